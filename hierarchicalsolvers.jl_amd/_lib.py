@@ -1,0 +1,165 @@
+"""ctypes binding of ``libhs_solver.so`` (C ABI: ``include/hs_solver.h``, ``include/hs_kernels.h``).
+
+There is no CPU fallback: if the shared library is missing, or it finds no HIP
+device, the calls raise.  ``build()`` compiles the library in-tree with hipcc
+(cross-compiles for gfx950 without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhs_solver.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+i64 = C.c_int64
+p_i64 = C.POINTER(C.c_int64)
+p_f64 = C.POINTER(C.c_double)
+
+
+class hs_options(C.Structure):
+    _fields_ = [
+        ("swlevel", i64), ("swsize", i64), ("atol", C.c_double), ("rtol", C.c_double), ("c_tol", C.c_double),
+        ("leafsize", i64), ("kest", i64), ("stepsize", i64), ("verbose", C.c_uint8),
+        ("keep_schur", C.c_uint8), ("reserved", C.c_uint8 * 6), ("seed", i64),
+    ]
+
+
+class hs_tree(C.Structure):
+    _fields_ = [
+        ("nnodes", i64), ("left", p_i64), ("right", p_i64),
+        ("int_ptr", p_i64), ("int_idx", p_i64), ("bnd_ptr", p_i64), ("bnd_idx", p_i64),
+        ("iloc_ptr", p_i64), ("iloc_idx", p_i64), ("bloc_ptr", p_i64), ("bloc_idx", p_i64),
+    ]
+
+
+class hs_stats(C.Structure):
+    _fields_ = [
+        ("n", i64), ("nnodes", i64), ("nlevels", i64), ("max_ni", i64), ("max_nb", i64),
+        ("flops_factor", C.c_double), ("bytes_factors", C.c_double), ("bytes_solve", C.c_double),
+        ("t_symbolic", C.c_double), ("t_upload", C.c_double), ("t_assemble", C.c_double), ("t_panel", C.c_double),
+        ("t_trsm", C.c_double), ("t_gemm", C.c_double), ("t_total", C.c_double), ("t_solve", C.c_double),
+        ("gemm_flops", C.c_double), ("gemm_launches", i64),
+    ]
+
+
+HS_OK = 0
+HS_ERR_ARGUMENT, HS_ERR_DIMENSION, HS_ERR_TREE, HS_ERR_SINGULAR = -1, -2, -3, -4
+HS_ERR_HSS_LEAF, HS_ERR_DEVICE, HS_ERR_NOMEM, HS_ERR_UNSUPPORTED = -5, -6, -7, -8
+HS_BLK_LU, HS_BLK_LBI, HS_BLK_UIB, HS_BLK_S = 0, 1, 2, 3
+
+# every symbol include/*.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "hs_options_default", "hs_factor_d", "hs_factor_z", "hs_ldiv_d", "hs_ldiv_z", "hs_ldiv_dev_d", "hs_ldiv_dev_z",
+    "hs_maxrank", "hs_is_complex", "hs_size", "hs_free", "hs_last_error", "hs_last_error_info", "hs_get_stats",
+    "hs_node_info", "hs_node_export", "hs_node_export_piv", "hs_device_info",
+    "hsk_gemm_d", "hsk_gemm_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak",
+]
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile ``libhs_solver.so`` for gfx950 in-tree (``make`` in ``csrc/``)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libhs_solver.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build() or `make -C {CSRC}`); "
+            "there is no CPU fallback"
+        )
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.hs_options_default.argtypes = [C.POINTER(hs_options)]
+    L.hs_options_default.restype = None
+    for f in (L.hs_factor_d, L.hs_factor_z):
+        f.argtypes = [i64, p_i64, p_i64, p_f64, C.POINTER(hs_tree), C.POINTER(hs_options), C.POINTER(vp)]
+        f.restype = C.c_int
+    for f in (L.hs_ldiv_d, L.hs_ldiv_z):
+        f.argtypes = [vp, p_f64, i64, p_f64, i64, i64, i64]
+        f.restype = C.c_int
+    for f in (L.hs_ldiv_dev_d, L.hs_ldiv_dev_z):
+        f.argtypes = [vp, vp, i64, vp, i64, i64, i64, vp]
+        f.restype = C.c_int
+    L.hs_maxrank.argtypes = [vp]
+    L.hs_maxrank.restype = i64
+    L.hs_is_complex.argtypes = [vp]
+    L.hs_is_complex.restype = C.c_int
+    L.hs_size.argtypes = [vp]
+    L.hs_size.restype = i64
+    L.hs_free.argtypes = [vp]
+    L.hs_free.restype = None
+    L.hs_last_error.argtypes = []
+    L.hs_last_error.restype = C.c_char_p
+    L.hs_last_error_info.argtypes = []
+    L.hs_last_error_info.restype = i64
+    L.hs_get_stats.argtypes = [vp, C.POINTER(hs_stats)]
+    L.hs_get_stats.restype = C.c_int
+    L.hs_node_info.argtypes = [vp, i64, p_i64, p_i64, p_i64]
+    L.hs_node_info.restype = C.c_int
+    L.hs_node_export.argtypes = [vp, i64, C.c_int, p_f64]
+    L.hs_node_export.restype = C.c_int
+    L.hs_node_export_piv.argtypes = [vp, i64, p_i64]
+    L.hs_node_export_piv.restype = C.c_int
+    L.hs_device_info.argtypes = [C.c_char_p, i64, p_i64, p_i64]
+    L.hs_device_info.restype = C.c_int
+    for f in (L.hsk_gemm_d, L.hsk_gemm_z):
+        f.argtypes = [i64, i64, i64, p_f64, i64, p_f64, i64, p_f64, i64, C.c_int, C.c_int, p_f64]
+        f.restype = C.c_int
+    for f in (L.hsk_front_factor_d, L.hsk_front_factor_z):
+        f.argtypes = [i64, i64, i64, p_f64, p_f64, p_f64, p_f64, p_i64, p_i64, p_f64]
+        f.restype = C.c_int
+    L.hsk_mfma_f64_peak.argtypes = [C.c_int, C.c_int]
+    L.hsk_mfma_f64_peak.restype = C.c_double
+    _lib = L
+    return L
+
+
+class DimensionMismatch(ValueError):
+    """Julia ``DimensionMismatch`` (blockmatrix.jl:13-16,116-117; nesteddissection.jl:107)."""
+
+
+class SingularException(ArithmeticError):
+    """``LinearAlgebra.SingularException`` -- what ``\\`` raises in the reference on an exactly singular block."""
+
+
+class DeviceError(RuntimeError):
+    """No usable gfx950 device / HIP runtime failure.  There is no CPU fallback."""
+
+
+class UnsupportedError(NotImplementedError):
+    pass
+
+
+def check(status):
+    if status == HS_OK:
+        return
+    msg = lib().hs_last_error().decode("utf-8", "replace")
+    info = lib().hs_last_error_info()
+    exc = {
+        HS_ERR_ARGUMENT: ValueError,  # ArgumentError
+        HS_ERR_DIMENSION: DimensionMismatch,
+        HS_ERR_TREE: RuntimeError,  # ErrorException (factorization.jl:25)
+        HS_ERR_SINGULAR: SingularException,
+        HS_ERR_HSS_LEAF: RuntimeError,
+        HS_ERR_DEVICE: DeviceError,
+        HS_ERR_NOMEM: MemoryError,
+        HS_ERR_UNSUPPORTED: UnsupportedError,
+    }.get(status, RuntimeError)
+    e = exc(msg)
+    e.info = info
+    e.status = status
+    raise e

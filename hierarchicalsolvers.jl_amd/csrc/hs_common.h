@@ -1,0 +1,183 @@
+// hs_common.h -- shared types of the gfx950 nested-dissection elimination kernels.
+//
+// Data layout in HBM.  One front = one node of the elimination tree with
+// ni eliminated ("int") and nb boundary ("bnd") DOFs, front order [int; bnd] -- the reference's
+// BlockMatrix quadruple Aii, Aib, Abi, Abb (src/factorization.jl:115-123):
+//
+//   LF  (m x ni, ld = ldl, m = ni+nb)  = [Aii; Abi]   -> after factor: [L\U ; Abi*U^-1]
+//   UR  (ni x nb, ld = ldu)            =  Aib         -> after factor:  L^-1 * P * Aib
+//   SB  (nb x nb, ld = lds)            =  Abb         -> after factor:  Schur complement S (temporary)
+//
+// all column-major like Julia's Matrix{T}.  LF and UR live in the permanent factor arena, SB in a
+// per-level scratch arena until the parent front has absorbed it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HS_PB 32          // panel width (columns factored per tournament-pivoting step)
+#define HS_CHUNK 256      // rows per tournament chunk (= threads per workgroup)
+#define HS_BIG (1 << 30)
+
+struct cplx {
+  double re, im;
+};
+
+__host__ __device__ inline cplx operator+(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__host__ __device__ inline cplx operator-(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__host__ __device__ inline cplx operator-(cplx a) { return {-a.re, -a.im}; }
+__host__ __device__ inline cplx operator*(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__host__ __device__ inline cplx operator/(cplx a, cplx b) {
+  // Smith's algorithm (what LAPACK's zladiv-free paths and Julia's `/` use for robustness)
+  if (fabs(b.re) >= fabs(b.im)) {
+    double r = b.im / b.re, d = b.re + b.im * r;
+    return {(a.re + a.im * r) / d, (a.im - a.re * r) / d};
+  } else {
+    double r = b.re / b.im, d = b.re * r + b.im;
+    return {(a.re * r + a.im) / d, (a.im * r - a.re) / d};
+  }
+}
+
+template <class T>
+struct Scal;
+template <>
+struct Scal<double> {
+  static __host__ __device__ inline double zero() { return 0.0; }
+  static __host__ __device__ inline double one() { return 1.0; }
+  static __host__ __device__ inline double abs1(double a) { return fabs(a); }  // idamax
+  static __host__ __device__ inline double fma(double a, double b, double c) { return ::fma(a, b, c); }
+  // c - a*b
+  static __host__ __device__ inline double fnma(double a, double b, double c) { return ::fma(-a, b, c); }
+};
+template <>
+struct Scal<cplx> {
+  static __host__ __device__ inline cplx zero() { return {0.0, 0.0}; }
+  static __host__ __device__ inline cplx one() { return {1.0, 0.0}; }
+  static __host__ __device__ inline double abs1(cplx a) { return fabs(a.re) + fabs(a.im); }  // izamax (cabs1)
+  static __host__ __device__ inline cplx fma(cplx a, cplx b, cplx c) {
+    return {::fma(a.re, b.re, ::fma(-a.im, b.im, c.re)), ::fma(a.re, b.im, ::fma(a.im, b.re, c.im))};
+  }
+  static __host__ __device__ inline cplx fnma(cplx a, cplx b, cplx c) {
+    return {::fma(-a.re, b.re, ::fma(a.im, b.im, c.re)), ::fma(-a.re, b.im, ::fma(-a.im, b.re, c.im))};
+  }
+};
+
+// Device-visible description of one front; an array of these (one per node of the current batch)
+// is uploaded once per level, every grouped kernel indexes it with blockIdx.y.
+template <class T>
+struct NodeDesc {
+  T* LF;
+  T* UR;
+  T* SB;
+  T* invL;       // ceil(ni/32) blocks of 32x32 (column-major, ld 32): inverse of the unit-lower diagonal block
+  T* invU;       // same for the upper diagonal block
+  int* ipiv;     // ni entries: LAPACK-style swap targets (0-based row inside the front)
+  int* cand0;    // tournament candidate lists (ping-pong)
+  int* cand1;
+  int* pivlist;  // HS_PB selected rows of the current panel
+  int* info;     // 0 = ok, else 1 + first column with an exactly zero pivot (SingularException)
+  const int* fidx;  // m global DOF ids (0-based), front order [int; bnd]
+  int ni, nb, m;
+  int ldl, ldu, lds;
+  int ni1, nb1;  // branch: sizes of the left child's contribution to int / bnd (front split points); leaf: ni, nb
+  int isleaf;
+  int node;      // post-order id
+};
+
+enum { HS_MAT_LF = 0, HS_MAT_UR = 1, HS_MAT_SB = 2 };
+
+// Sub-block op of the recursive LU on a batch of fronts: ranges are given in front coordinates and
+// clipped per node to the extents of the matrices they address.
+struct GemmOp {
+  int cmat, bmat;  // C and B live in LF / UR / SB; A is always LF
+  int r0, r1;      // C rows   (A rows are the same, shifted by ni when C is SB)
+  int c0, c1;      // C cols = B cols
+  int k0, k1;      // A cols = B rows (always inside [0, ni))
+};
+
+// plain problem (test hooks, root Schur, compressed path)
+template <class T>
+struct GemmProb {
+  const T* A;
+  const T* B;
+  T* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+};
+
+template <class T>
+__device__ inline void mat_of(const NodeDesc<T>& nd, int which, T*& p, int& ld, int& rows, int& cols) {
+  if (which == HS_MAT_LF) {
+    p = nd.LF; ld = nd.ldl; rows = nd.m; cols = nd.ni;
+  } else if (which == HS_MAT_UR) {
+    p = nd.UR; ld = nd.ldu; rows = nd.ni; cols = nd.nb;
+  } else {
+    p = nd.SB; ld = nd.lds; rows = nd.nb; cols = nd.nb;
+  }
+}
+
+// ---- launch API (implemented in the kernels_*.hip files) -------------------------------------
+template <class T>
+void launch_gemm_op(const NodeDesc<T>* dnodes, int nbatch, int maxM, int maxN, const GemmOp& op, hipStream_t s);
+template <class T>
+void launch_gemm_probs(const GemmProb<T>* dprobs, int nprob, int maxM, int maxN, int accumulate_minus, hipStream_t s);
+
+template <class T>
+void launch_tournament_round(const NodeDesc<T>* dnodes, int nbatch, int pb, int round, int maxchunks, hipStream_t s);
+template <class T>
+void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, hipStream_t s);
+template <class T>
+void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, hipStream_t s);
+template <class T>
+void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1, int k0, int k1, int maxcols, hipStream_t s);
+template <class T>
+void launch_trsm_blk(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int c0, int c1, int maxcols, hipStream_t s);
+
+template <class T>
+void launch_mark(const NodeDesc<T>* dnodes, int nbatch, int maxm, int* own, int* pos, hipStream_t s);
+template <class T>
+void launch_gather(const NodeDesc<T>* dnodes, int nbatch, int maxm, const int64_t* colptr, const int32_t* rowval,
+                   const T* nzval, const int* own, const int* pos, hipStream_t s);
+template <class T>
+struct ScatterDesc {  // child Schur complement -> parent front
+  const T* S;         // child's SB (nbc x nbc, ld = lds)
+  const int* cmap;    // nbc entries: position in the parent front, -1 = dropped
+  int nbc, lds;
+  int parent;         // index of the parent in the current batch's NodeDesc array
+};
+template <class T>
+void launch_scatter(const NodeDesc<T>* dnodes, const ScatterDesc<T>* dsc, int nsc, int maxnbc, hipStream_t s);
+
+// solve phase (kernels_solve.hip); one right-hand side per launch
+template <class T>
+struct SolveNode {
+  const T* LF;
+  const T* UR;
+  const T* invL;
+  const T* invU;
+  const int* rperm;  // ni: (P x)[i] = x[rperm[i]]
+  const int* fidx;   // m global ids (0-based), front order [int; bnd]
+  int ni, nb, m, ldl, ldu;
+  long long woff;    // offset of this node's ni-segment in the work vectors
+  long long poff;    // offset of this node's partial-sum scratch (ceil(nb/512) * ni entries)
+};
+template <class T>
+void launch_fwd_gather(const SolveNode<T>* dn, int nbatch, int maxni, const T* b, T* w, hipStream_t s);
+template <class T>
+void launch_fwd_step(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w, T* y, T* b, hipStream_t s);
+template <class T>
+void launch_int_update(const SolveNode<T>* dn, int nbatch, int maxni, int maxnb, const T* b, T* part, const T* y, T* w, hipStream_t s);
+template <class T>
+void launch_bwd_step(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s);
+template <class T>
+void launch_bwd_scatter(const SolveNode<T>* dn, int nbatch, int maxni, T* b, const T* x, hipStream_t s);
+
+void hs_set_error(int code, long long info, const char* fmt, ...);
+
+#define HS_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      hs_set_error(-6, 0, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      throw (int)-6;                                                                          \
+    }                                                                                         \
+  } while (0)

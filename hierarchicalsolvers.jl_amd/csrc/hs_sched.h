@@ -1,0 +1,92 @@
+// hs_sched.h -- the level-batched recursive LU schedule (host side; launches only).
+//
+// Recursive (binary-splitting) right-looking LU over a batch of fronts: all fronts of one tree level
+// walk the same split tree over global column indices (multiples of 32), each clipping the ranges
+// to its own ni / nb inside the kernels.  Every trailing update is one MFMA GEMM whose inner
+// dimension is the width of the finished left half, so almost all flops run at large K.
+#pragma once
+#include <algorithm>
+#include "../../include/hs_solver.h"
+#include "hs_common.h"
+
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct Sched {
+  const NodeDesc<T>* dn;
+  int nbatch, maxni, maxnb, maxm;
+  hipStream_t s;
+  hs_stats* st;
+
+  int rows_of(int mat) const { return mat == HS_MAT_LF ? maxm : (mat == HS_MAT_UR ? maxni : maxnb); }
+  int cols_of(int mat) const { return mat == HS_MAT_LF ? maxni : maxnb; }
+
+  void gemm(int cmat, int bmat, int r0, int r1, int c0, int c1, int k0, int k1) {
+    GemmOp op{cmat, bmat, r0, r1, c0, c1, k0, k1};
+    int M = std::min(r1, rows_of(cmat)) - r0, N = std::min(c1, cols_of(cmat)) - c0, K = std::min(k1, maxni) - k0;
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    launch_gemm_op<T>(dn, nbatch, M, N, op, s);
+    st->gemm_launches++;
+  }
+  void panel(int pb) {
+    int c0 = pb * HS_PB;
+    if (c0 >= maxni) return;
+    int cnt = maxni - c0, nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
+    for (int round = 0;; ++round) {
+      launch_tournament_round<T>(dn, nbatch, pb, round, nch, s);
+      if (nch == 1) break;
+      cnt = nch * HS_PB;
+      nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
+    }
+    launch_panel_pivot<T>(dn, nbatch, pb, s);
+    launch_panel_l21<T>(dn, nbatch, pb, maxm - c0, s);
+  }
+  void laswp(int mat, int c0, int c1, int k0, int k1) {
+    int nc = std::min(c1, cols_of(mat)) - c0;
+    if (nc <= 0 || k0 >= maxni) return;
+    launch_laswp<T>(dn, nbatch, mat, c0, c1, k0, k1, nc, s);
+  }
+  // X[r0:r1, c0:c1) <- L[r0:r1, r0:r1]^-1 X
+  void trsm_rec(int mat, int r0, int r1, int c0, int c1) {
+    if (r0 >= maxni) return;
+    int nc = std::min(c1, cols_of(mat)) - c0;
+    if (nc <= 0) return;
+    if (r1 - r0 == HS_PB) {
+      launch_trsm_blk<T>(dn, nbatch, mat, r0, c0, c1, nc, s);
+      return;
+    }
+    int mid = (r0 + r1) / 2;
+    trsm_rec(mat, r0, mid, c0, c1);
+    if (mid < maxni) {
+      gemm(mat, mat, mid, r1, c0, c1, r0, mid);
+      trsm_rec(mat, mid, r1, c0, c1);
+    }
+  }
+  void lu_rec(int c0, int c1) {
+    if (c0 >= maxni) return;
+    if (c1 - c0 == HS_PB) {
+      panel(c0 / HS_PB);
+      return;
+    }
+    int mid = (c0 + c1) / 2;
+    lu_rec(c0, mid);
+    if (mid < maxni) {
+      laswp(HS_MAT_LF, mid, c1, c0, mid);
+      trsm_rec(HS_MAT_LF, c0, mid, mid, c1);
+      gemm(HS_MAT_LF, HS_MAT_LF, mid, HS_BIG, mid, c1, c0, mid);
+      lu_rec(mid, c1);
+      laswp(HS_MAT_LF, c0, mid, mid, c1);
+    }
+  }
+  void factor_fronts() {
+    if (maxni <= 0) return;
+    int P2 = HS_PB;
+    while (P2 < maxni) P2 *= 2;
+    lu_rec(0, P2);
+    if (maxnb > 0) {
+      laswp(HS_MAT_UR, 0, HS_BIG, 0, P2);
+      trsm_rec(HS_MAT_UR, 0, P2, 0, HS_BIG);
+      gemm(HS_MAT_SB, HS_MAT_UR, 0, HS_BIG, 0, HS_BIG, 0, HS_BIG);
+    }
+  }
+};
+

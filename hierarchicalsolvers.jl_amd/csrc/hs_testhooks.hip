@@ -1,0 +1,167 @@
+// hs_testhooks.hip -- kernel-level entry points used only by tests/ (declared in include/hs_kernels.h).
+// They drive exactly the kernels hs_factor_* uses, on caller-supplied dense data, so every kernel
+// can be checked against the oracle in isolation.
+#include <cstring>
+#include <vector>
+
+#include "../../include/hs_kernels.h"
+#include "hs_sched.h"
+
+#define CK(call)                                                                                   \
+  do {                                                                                             \
+    hipError_t e__ = (call);                                                                       \
+    if (e__ != hipSuccess) {                                                                       \
+      hs_set_error(HS_ERR_DEVICE, 0, "%s failed: %s", #call, hipGetErrorString(e__));              \
+      return HS_ERR_DEVICE;                                                                        \
+    }                                                                                              \
+  } while (0)
+
+template <class T>
+static int gemm_hook(int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int minus,
+                     int repeat, double* ms_out) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+    hs_set_error(HS_ERR_DEVICE, 0, "no HIP device available");
+    return HS_ERR_DEVICE;
+  }
+  T *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  GemmProb<T>* dp = nullptr;
+  CK(hipMalloc((void**)&dA, sizeof(T) * (size_t)lda * K + 16));
+  CK(hipMalloc((void**)&dB, sizeof(T) * (size_t)ldb * N + 16));
+  CK(hipMalloc((void**)&dC, sizeof(T) * (size_t)ldc * N + 16));
+  CK(hipMalloc((void**)&dp, sizeof(GemmProb<T>)));
+  CK(hipMemcpy(dA, A, sizeof(T) * (size_t)lda * K, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB, B, sizeof(T) * (size_t)ldb * N, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dC, C, sizeof(T) * (size_t)ldc * N, hipMemcpyHostToDevice));
+  GemmProb<T> p{dA, dB, dC, (int)M, (int)N, (int)K, (int)lda, (int)ldb, (int)ldc};
+  CK(hipMemcpy(dp, &p, sizeof p, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  launch_gemm_probs<T>(dp, 1, (int)M, (int)N, minus, 0);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(C, dC, sizeof(T) * (size_t)ldc * N, hipMemcpyDeviceToHost));
+  if (repeat > 0) {
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < repeat; ++r) launch_gemm_probs<T>(dp, 1, (int)M, (int)N, minus, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / repeat;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dC);
+  (void)hipFree(dp);
+  return HS_OK;
+}
+
+extern "C" int hsk_gemm_d(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
+                          int64_t ldc, int minus, int repeat, double* ms_out) {
+  return gemm_hook<double>(M, N, K, A, lda, B, ldb, C, ldc, minus, repeat, ms_out);
+}
+extern "C" int hsk_gemm_z(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
+                          int64_t ldc, int minus, int repeat, double* ms_out) {
+  return gemm_hook<cplx>(M, N, K, (const cplx*)A, lda, (const cplx*)B, ldb, (cplx*)C, ldc, minus, repeat, ms_out);
+}
+
+// Factor `count` identical-shape dense fronts F[k] ((ni+nb)^2, column-major, front order [int;bnd]) in one batch.
+template <class T>
+static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outLF, T* outUR, T* outSB, int64_t* out_rperm, int64_t* info,
+                      double* ms_out) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+    hs_set_error(HS_ERR_DEVICE, 0, "no HIP device available");
+    return HS_ERR_DEVICE;
+  }
+  const int m = (int)(ni + nb);
+  const int ldl = (m + 1) / 2 * 2, ldu = ((int)ni + 1) / 2 * 2 > 0 ? ((int)ni + 1) / 2 * 2 : 2, lds = ((int)nb + 1) / 2 * 2 > 0 ? ((int)nb + 1) / 2 * 2 : 2;
+  const int nblk = ((int)ni + HS_PB - 1) / HS_PB;
+  const size_t eLF = (size_t)ldl * ni + 32, eUR = (size_t)ldu * nb + 32, eSB = (size_t)lds * nb + 32, eInv = (size_t)2 * nblk * 1024 + 32;
+  const int ncand = (((int)ni + HS_CHUNK - 1) / HS_CHUNK + 1) * HS_PB;
+  const size_t eInt = (size_t)ni + 2 * ncand + HS_PB + 1;
+  T* dbuf = nullptr;
+  int* dint = nullptr;
+  NodeDesc<T>* dn = nullptr;
+  const size_t per = eLF + eUR + eSB + eInv;
+  CK(hipMalloc((void**)&dbuf, sizeof(T) * per * count));
+  CK(hipMalloc((void**)&dint, sizeof(int) * eInt * count));
+  CK(hipMalloc((void**)&dn, sizeof(NodeDesc<T>) * count));
+  CK(hipMemset(dbuf, 0, sizeof(T) * per * count));
+  CK(hipMemset(dint, 0, sizeof(int) * eInt * count));
+  std::vector<NodeDesc<T>> hn(count);
+  for (int64_t k = 0; k < count; ++k) {
+    NodeDesc<T>& d = hn[k];
+    memset(&d, 0, sizeof d);
+    d.LF = dbuf + per * k;
+    d.UR = d.LF + eLF;
+    d.SB = d.UR + eUR;
+    d.invL = d.SB + eSB;
+    d.invU = d.invL + (size_t)nblk * 1024;
+    d.ipiv = dint + eInt * k;
+    d.cand0 = d.ipiv + ni;
+    d.cand1 = d.cand0 + ncand;
+    d.pivlist = d.cand1 + ncand;
+    d.info = d.pivlist + HS_PB;
+    d.ni = (int)ni; d.nb = (int)nb; d.m = m;
+    d.ldl = ldl; d.ldu = ldu; d.lds = lds;
+    d.ni1 = (int)ni; d.nb1 = (int)nb; d.isleaf = 1; d.node = (int)k;
+    const T* Fk = F + (size_t)m * m * k;
+    if (ni > 0) CK(hipMemcpy2D(d.LF, sizeof(T) * ldl, Fk, sizeof(T) * m, sizeof(T) * m, ni, hipMemcpyHostToDevice));
+    if (ni > 0 && nb > 0) CK(hipMemcpy2D(d.UR, sizeof(T) * ldu, Fk + (size_t)m * ni, sizeof(T) * m, sizeof(T) * ni, nb, hipMemcpyHostToDevice));
+    if (nb > 0) CK(hipMemcpy2D(d.SB, sizeof(T) * lds, Fk + (size_t)m * ni + ni, sizeof(T) * m, sizeof(T) * nb, nb, hipMemcpyHostToDevice));
+  }
+  CK(hipMemcpy(dn, hn.data(), sizeof(NodeDesc<T>) * count, hipMemcpyHostToDevice));
+  hs_stats st;
+  memset(&st, 0, sizeof st);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, 0));
+  Sched<T> sch{dn, (int)count, (int)ni, (int)nb, m, 0, &st};
+  sch.factor_fronts();
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_out) *ms_out = ms;
+  CK(hipDeviceSynchronize());
+  std::vector<int> ip(ni);
+  for (int64_t k = 0; k < count; ++k) {
+    NodeDesc<T>& d = hn[k];
+    if (ni > 0 && outLF) CK(hipMemcpy2D(outLF + (size_t)m * ni * k, sizeof(T) * m, d.LF, sizeof(T) * ldl, sizeof(T) * m, ni, hipMemcpyDeviceToHost));
+    if (ni > 0 && nb > 0 && outUR) CK(hipMemcpy2D(outUR + (size_t)ni * nb * k, sizeof(T) * ni, d.UR, sizeof(T) * ldu, sizeof(T) * ni, nb, hipMemcpyDeviceToHost));
+    if (nb > 0 && outSB) CK(hipMemcpy2D(outSB + (size_t)nb * nb * k, sizeof(T) * nb, d.SB, sizeof(T) * lds, sizeof(T) * nb, nb, hipMemcpyDeviceToHost));
+    if (ni > 0) CK(hipMemcpy(ip.data(), d.ipiv, sizeof(int) * ni, hipMemcpyDeviceToHost));
+    if (out_rperm) {
+      int64_t* rp = out_rperm + ni * k;
+      for (int64_t i = 0; i < ni; ++i) rp[i] = i;
+      for (int64_t i = 0; i < ni; ++i) {
+        int p = ip[i];
+        if (p < 0 || p >= ni) p = (int)i;
+        int64_t t = rp[i]; rp[i] = rp[p]; rp[p] = t;
+      }
+    }
+    int inf = 0;
+    CK(hipMemcpy(&inf, d.info, sizeof(int), hipMemcpyDeviceToHost));
+    if (info) info[k] = inf;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(dbuf);
+  (void)hipFree(dint);
+  (void)hipFree(dn);
+  return HS_OK;
+}
+
+extern "C" int hsk_front_factor_d(int64_t count, int64_t ni, int64_t nb, const double* F, double* outLF, double* outUR, double* outSB,
+                                  int64_t* out_rperm, int64_t* info, double* ms_out) {
+  return front_hook<double>(count, ni, nb, F, outLF, outUR, outSB, out_rperm, info, ms_out);
+}
+extern "C" int hsk_front_factor_z(int64_t count, int64_t ni, int64_t nb, const double* F, double* outLF, double* outUR, double* outSB,
+                                  int64_t* out_rperm, int64_t* info, double* ms_out) {
+  return front_hook<cplx>(count, ni, nb, (const cplx*)F, (cplx*)outLF, (cplx*)outUR, (cplx*)outSB, out_rperm, info, ms_out);
+}

@@ -1,0 +1,40 @@
+/*
+ * hs_kernels.h -- kernel-level test hooks of libhs_solver (used by tests/ only).
+ *
+ * These drive the same HIP kernels the hot path (hs_factor_* / hs_ldiv_* in hs_solver.h) launches,
+ * on caller-supplied dense host data, so each kernel can be checked against the oracle alone.
+ * Column-major everywhere; complex = interleaved (re, im) doubles (Julia ComplexF64).
+ */
+#ifndef HS_KERNELS_H
+#define HS_KERNELS_H
+#include <stdint.h>
+#include "hs_solver.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* C = C - A*B (minus != 0) or C = A*B (minus == 0) with the MFMA GEMM kernel
+ * (the contraction of src/factorization.jl:40,72 and src/blockmatrix.jl:97,118).
+ * repeat > 0 additionally times `repeat` back-to-back launches (ms per launch in *ms_out). */
+int hsk_gemm_d(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb,
+               double* C, int64_t ldc, int minus, int repeat, double* ms_out);
+int hsk_gemm_z(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb,
+               double* C, int64_t ldc, int minus, int repeat, double* ms_out);
+
+/* Eliminate the first ni DOFs of `count` dense fronts F[k] ((ni+nb) x (ni+nb), front order [int; bnd]):
+ * the per-front work of _factor_leaf / _factor_branch (src/factorization.jl:30-42, 62-75).
+ *   outLF  (ni+nb) x ni : [L\U of P*Aii ; Abi*U^-1]      outUR  ni x nb : L^-1*P*Aib
+ *   outSB  nb x nb      : Abb - Abi*Aii^-1*Aib           out_rperm ni   : (P x)[i] = x[rperm[i]] (0-based)
+ *   info[k]             : 0, or 1 + first column with an exactly zero pivot */
+int hsk_front_factor_d(int64_t count, int64_t ni, int64_t nb, const double* F, double* outLF, double* outUR,
+                       double* outSB, int64_t* out_rperm, int64_t* info, double* ms_out);
+int hsk_front_factor_z(int64_t count, int64_t ni, int64_t nb, const double* F, double* outLF, double* outUR,
+                       double* outSB, int64_t* out_rperm, int64_t* info, double* ms_out);
+
+/* Measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on every CU (roofline denominator). */
+double hsk_mfma_f64_peak(int waves_per_simd, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

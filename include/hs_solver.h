@@ -1,0 +1,149 @@
+/*
+ * hs_solver.h -- C ABI of the MI355X-native nested-dissection elimination.
+ *
+ * Drop-in boundary for ONE hot path of bonevbs/HierarchicalSolvers.jl:
+ *
+ *   factor(A::SparseMatrixCSC{T}, nd, nd_loc, opts; kw...) -> FactorNode{T}
+ *                                      (reference src/factorization.jl:5-11)
+ *   ldiv!(C, F, B), ldiv!(F, B)        (reference src/factornode.jl:62-74)
+ *   maxrank(F)                         (reference src/factornode.jl:49-57)
+ *
+ * The reference has no FFI of its own (it is pure Julia); these entry points
+ * are what a Julia `ccall` shim for that path binds (INTEGRATION.md shows the
+ * shim).  Plain pointers and sizes only; all index arrays are 1-based int64
+ * exactly as the Julia host holds them (SparseMatrixCSC.colptr/rowval, the
+ * index vectors of the NestedDissection trees), converted inside the library.
+ *
+ * Threading: a call blocks the calling thread.  One handle must not be used
+ * from two threads at once; distinct handles may.  hs_free is idempotent per
+ * handle pointer value being NULL-safe and may be called from any thread
+ * (Julia finalizer).  Errors: every int-returning function returns HS_OK (0)
+ * or a negative hs_status; hs_last_error() returns the thread-local message.
+ */
+#ifndef HS_SOLVER_H
+#define HS_SOLVER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum hs_status {
+  HS_OK = 0,
+  HS_ERR_ARGUMENT = -1,  /* Julia ArgumentError   (HierarchicalSolvers.jl:74-78, nesteddissection.jl:111) */
+  HS_ERR_DIMENSION = -2, /* Julia DimensionMismatch (blockmatrix.jl:13-16,116-117; nesteddissection.jl:107) */
+  HS_ERR_TREE = -3,      /* ErrorException "Expected nested dissection to be a binary tree..." (factorization.jl:25) */
+  HS_ERR_SINGULAR = -4,  /* LinearAlgebra.SingularException raised by `\` in the reference; info = node id */
+  HS_ERR_HSS_LEAF = -5,  /* error("One of the Schur complements turned into a leaf. Aborting.") (factorization.jl:164) */
+  HS_ERR_DEVICE = -6,    /* HIP runtime failure / no gfx950 device: the library never falls back to the CPU */
+  HS_ERR_NOMEM = -7,     /* device or host allocation failed */
+  HS_ERR_UNSUPPORTED = -8
+} hs_status;
+
+/* POD mirror of `mutable struct SolverOptions` (HierarchicalSolvers.jl:30-40), same order,
+ * followed by extension fields (zero = default). */
+typedef struct hs_options {
+  int64_t swlevel;  /* compress the top `swlevel` levels; <0 counts from the leaves (factorization.jl:8) */
+  int64_t swsize;   /* minimum |bnd| for compression */
+  double atol;
+  double rtol;
+  double c_tol;     /* validated, never consumed by the reference (factorization.jl:97-100) */
+  int64_t leafsize; /* HSS leaf size */
+  int64_t kest;     /* rank estimate for randomized compression; <0 => ceil(rank(L)/2) (factorization.jl:102-104) */
+  int64_t stepsize; /* validated, never consumed by the reference */
+  uint8_t verbose;
+  /* ---- extensions ---- */
+  uint8_t keep_schur; /* debug: retain every node's Schur complement S for hs_node_export */
+  uint8_t reserved[6];
+  int64_t seed;       /* RNG seed of the randomized compression (reference: Random.seed!(123), test/rungmres.jl:7) */
+} hs_options;
+
+/* Defaults of the reference's kw-constructor (HierarchicalSolvers.jl:43-54): 5,1,1e-6,1e-6,0.5,32,-1,10,false */
+void hs_options_default(hs_options* opts);
+
+/* Flat post-ordered form of the two trees `symfact!` returns (nesteddissection.jl:29-69).
+ * Node ids are 0-based post-order positions (children before parents, root = nnodes-1), -1 = no child.
+ * *_idx hold 1-based values as Julia holds them; *_ptr are 0-based offsets, length nnodes+1.
+ *   int_idx  : nd.int      (global DOF ids eliminated at the node)
+ *   bnd_idx  : nd.bnd      (global DOF ids of the node's boundary)
+ *   iloc_idx : nd_loc.int  (positions in the node's OWN bnd that land in the parent's int)
+ *   bloc_idx : nd_loc.bnd  (positions in the node's OWN bnd that land in the parent's bnd)
+ */
+typedef struct hs_tree {
+  int64_t nnodes;
+  const int64_t* left;
+  const int64_t* right;
+  const int64_t* int_ptr;
+  const int64_t* int_idx;
+  const int64_t* bnd_ptr;
+  const int64_t* bnd_idx;
+  const int64_t* iloc_ptr;
+  const int64_t* iloc_idx;
+  const int64_t* bloc_ptr;
+  const int64_t* bloc_idx;
+} hs_tree;
+
+typedef struct hs_handle hs_handle; /* opaque: owns every device allocation of one factorization */
+
+/* factor(A, nd, nd_loc, opts) for T = Float64 / ComplexF64 (factorization.jl:5).
+ * A is n x n CSC with 1-based colptr[n+1], rowval[nnz]; nzval_z is interleaved (re,im) = Julia ComplexF64.
+ * Inputs are borrowed for the duration of the call.  On success *out owns the device-resident factors. */
+int hs_factor_d(int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                const hs_tree* tree, const hs_options* opts, hs_handle** out);
+int hs_factor_z(int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval_z,
+                const hs_tree* tree, const hs_options* opts, hs_handle** out);
+
+/* ldiv!(C, F, B): C = F^{-1} B for n x nrhs column-major host arrays (factornode.jl:62-74).
+ * C may alias B (true in-place semantics; the reference's 2-arg form allocates). */
+int hs_ldiv_d(hs_handle* F, double* C, int64_t ldc, const double* B, int64_t ldb, int64_t n, int64_t nrhs);
+int hs_ldiv_z(hs_handle* F, double* C, int64_t ldc, const double* B, int64_t ldb, int64_t n, int64_t nrhs);
+
+/* Same with DEVICE pointers on HIP stream `stream` (hipStream_t, NULL = default), asynchronous:
+ * for an on-device Krylov caller (gmres(...; Pr=F), test/rungmres.jl:47-48). */
+int hs_ldiv_dev_d(hs_handle* F, double* dC, int64_t ldc, const double* dB, int64_t ldb, int64_t n, int64_t nrhs, void* stream);
+int hs_ldiv_dev_z(hs_handle* F, double* dC, int64_t ldc, const double* dB, int64_t ldb, int64_t n, int64_t nrhs, void* stream);
+
+int64_t hs_maxrank(const hs_handle* F); /* factornode.jl:49-57; 0 for the dense path */
+int hs_is_complex(const hs_handle* F);  /* eltype(F) == ComplexF64 */
+int64_t hs_size(const hs_handle* F);    /* n */
+void hs_free(hs_handle* F);
+const char* hs_last_error(void);
+int64_t hs_last_error_info(void); /* e.g. node id of a singular front */
+
+/* ---- introspection (metrics the reference lacks) ---- */
+typedef struct hs_stats {
+  int64_t n, nnodes, nlevels;
+  int64_t max_ni, max_nb;
+  double flops_factor;   /* sum of F(ni,nb) = 2/3 ni^3 + 2 ni^2 nb + 2 ni nb^2 (x4 for complex), SURVEY.md 8(d) */
+  double bytes_factors;  /* device bytes held by the factors */
+  double bytes_solve;    /* algorithmic bytes one ldiv! with nrhs=1 must read */
+  double t_symbolic, t_upload, t_assemble, t_panel, t_trsm, t_gemm, t_total; /* seconds, device time of last hs_factor */
+  double t_solve;        /* seconds, device time of last hs_ldiv */
+  double gemm_flops;     /* flops executed by the MFMA GEMM kernel in the last hs_factor */
+  int64_t gemm_launches;
+} hs_stats;
+int hs_get_stats(const hs_handle* F, hs_stats* out);
+
+/* per-node sizes (post-order id): ni, nb, level (root = 1) */
+int hs_node_info(const hs_handle* F, int64_t node, int64_t* ni, int64_t* nb, int64_t* level);
+
+/* Export one node's stored blocks to host (column-major, tight leading dimension), for parity tests:
+ *   HS_BLK_LU  : ni x ni   packed L\U of the pivoted interior block  (P*Aii = L*U)
+ *   HS_BLK_LBI : nb x ni   Abi * U^{-1}
+ *   HS_BLK_UIB : ni x nb   L^{-1} * P * Aib
+ *   HS_BLK_S   : nb x nb   Schur complement in the node's own bnd order (needs opts.keep_schur)
+ * out must hold rows*cols elements of T (2 doubles per element for complex).
+ *   hs_node_export_piv: ni int64 values, 0-based row permutation p with (P*x)[i] = x[p[i]].
+ * From these: D = P'LU, L = Lbi*L^{-1}*P, R = U^{-1}*Uib  (FactorNode fields, factornode.jl:7-12). */
+enum { HS_BLK_LU = 0, HS_BLK_LBI = 1, HS_BLK_UIB = 2, HS_BLK_S = 3 };
+int hs_node_export(const hs_handle* F, int64_t node, int which, double* out);
+int hs_node_export_piv(const hs_handle* F, int64_t node, int64_t* out);
+
+/* Library/device identification: fills name (e.g. "gfx950") and returns the CU count, or <0 if no usable device. */
+int hs_device_info(char* arch_name, int64_t len, int64_t* cu_count, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HS_SOLVER_H */

@@ -1,0 +1,202 @@
+"""Parity tests proper: hs_factor_* / hs_ldiv_* (HIP, through the C ABI) against the CPU oracle and
+against SuperLU on the same seeded inputs.
+
+Tolerances (FP64, stated per SURVEY.md section 8(c)): the dense path is exact, so
+  * solution:        ||x - x_ref|| / ||x_ref|| <= 1e-10  (oracle and splu),
+  * per-node blocks: relative Frobenius error <= 1e-9 on D, L, R, S of every node vs the oracle.
+Pivot orders differ (tournament pivoting here, LAPACK partial pivoting in Julia/the oracle), so
+block-wise agreement is to rounding, not bitwise.
+"""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from helpers import prepare, relerr
+from oracle import hs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SOL_TOL = 1e-10
+BLK_TOL = 1e-9
+
+
+def _solve_check(hs, P, F, nrhs=1, seed=0):
+    n = P["A"].shape[0]
+    rng = np.random.default_rng(seed)
+    B = rng.standard_normal((n, nrhs))
+    if F.dtype.kind == "c":
+        B = B + 1j * rng.standard_normal((n, nrhs))
+    X = hs.ldiv(F, B if nrhs > 1 else B[:, 0])
+    Xr = spla.splu(P["A"]).solve(B if nrhs > 1 else B[:, 0])
+    assert relerr(X, Xr) < SOL_TOL
+    res = np.linalg.norm(P["A"] @ X - (B if nrhs > 1 else B[:, 0])) / np.linalg.norm(B)
+    assert res < 1e-11
+    return X
+
+
+@pytest.mark.parametrize("name", ["poisson2d_p1_h64_nmax100", "helmholtz2d_p1_h64_nmax100"])
+def test_scenario_vs_oracle_blocks(hs, name):
+    """configs[0] (and its complex twin): every node's D, L, R, S and the solution vs the oracle."""
+    P = prepare(hs, name)
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0, keep_schur=True)
+    Fo = O.factor(P["A"], P["ond"], P["ond_loc"], swlevel=0)
+    onodes = []
+
+    def walk(f):
+        if f.left is not None:
+            walk(f.left)
+        if f.right is not None:
+            walk(f.right)
+        onodes.append(f)
+
+    walk(Fo)
+    assert len(onodes) == F.nnodes
+    for k, fo in enumerate(onodes):
+        ni, nb, _ = F.node_info(k)
+        assert (ni, nb) == (len(fo.int), len(fo.bnd))
+        rb = F.reference_blocks(k, with_schur=True)
+        D = fo.D.B.dense() if isinstance(fo.D, O.BlockFactorization) else fo.D
+        if isinstance(fo.D, O.BlockFactorization):
+            # reference stores (A11, A12, A21, S22) unfactored: rebuild Aii = [A11 A12; A21 S22 + A21 A11^-1 A12]
+            Bm = fo.D.B
+            D = np.block([[Bm.A11, Bm.A12], [Bm.A21, Bm.A22 + Bm.A21 @ np.linalg.solve(Bm.A11, Bm.A12)]])
+        assert relerr(rb["D"], D) < BLK_TOL, k
+        if nb:
+            assert relerr(rb["L"], O._dense(fo.L)) < BLK_TOL, k
+            assert relerr(rb["R"], O._dense(fo.R)) < BLK_TOL, k
+            # oracle S is S[perm,perm] with perm = [int_loc; bnd_loc]; ours is in the node's own bnd order
+            perm = np.concatenate([fo.int_loc, fo.bnd_loc]) - 1
+            assert relerr(rb["S"][np.ix_(perm, perm)], O._dense(fo.S)) < BLK_TOL, k
+    x = hs.ldiv(F, P["b"])
+    xo = O.ldiv(Fo, P["b"])
+    assert relerr(x, xo) < SOL_TOL
+    assert relerr(x, spla.splu(P["A"]).solve(P["b"])) < SOL_TOL
+    assert hs.maxrank(F) == O.maxrank(Fo) == 0
+
+
+@pytest.mark.parametrize(
+    "name", ["poisson2d_p1_h128_nmax100", "helmholtz2d_p1_h128_nmax100", "poisson3d_32", "helmholtz3d_32"]
+)
+def test_exact_solve_vs_splu(hs, name):
+    P = prepare(hs, name, rhs="randn")
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0)
+    x = hs.ldiv(F, P["b"])
+    assert relerr(x, spla.splu(P["A"]).solve(P["b"])) < SOL_TOL
+    _solve_check(hs, P, F, nrhs=3, seed=2)
+    st = F.stats()
+    assert st["flops_factor"] == pytest.approx(O.tree_flops(P["ond"]) * (4 if F.dtype.kind == "c" else 1), rel=1e-12)
+
+
+@pytest.mark.parametrize("shape,nmax,kind", [((7, 5), 6, "poisson"), ((9, 9), 12, "helmholtz"), ((6, 6, 6), 30, "poisson"), ((3, 3), 100, "poisson"), ((40, 3), 9, "poisson")])
+def test_small_and_ragged_trees(hs, shape, nmax, kind):
+    """tiny / ragged trees: single-leaf tree, leaves at different depths, fronts smaller than one panel."""
+    P = prepare(hs, shape, kind=kind, nmax=nmax, rhs="randn")
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0)
+    Fo = O.factor(P["A"], P["ond"], P["ond_loc"], swlevel=0)
+    assert relerr(hs.ldiv(F, P["b"]), O.ldiv(Fo, P["b"])) < SOL_TOL
+
+
+def test_unpermuted_tree_general_index_sets(hs):
+    """`factor` does not need the postorder permutation (the script applies it, test/rungmres.jl:17-19):
+    scattered, non-contiguous int sets must give the same solution."""
+    A, b, nd = hs.problems.make_problem((17, 13), kind="poisson", nmax=20, rhs="randn")
+    nd, nd_loc = hs.symfact(nd)
+    F = hs.factor(A, nd, nd_loc, swlevel=0)
+    assert relerr(hs.ldiv(F, b), spla.splu(A.tocsc()).solve(b)) < SOL_TOL
+
+
+def test_root_with_boundary(hs):
+    """A tree whose root keeps a boundary: ldiv! then solves with the root Schur complement
+    (`C[F.bnd,:] = F.S \\ C[F.bnd,:]`, factornode.jl:72)."""
+    A, b, nd = hs.problems.make_problem((12, 10), kind="poisson", nmax=16, rhs="randn")
+    sub = nd.left  # left subtree: its bnd is non-empty; restrict A to the subtree's DOFs
+    dofs = np.sort(np.concatenate([x.int for x in hs.postorder_nodes(sub)] + [sub.bnd]))
+    remap = np.zeros(A.shape[0] + 1, dtype=np.int64)
+    remap[dofs] = np.arange(1, len(dofs) + 1)
+    for x in hs.postorder_nodes(sub):
+        x.int, x.bnd = remap[x.int], remap[x.bnd]
+    As = A[dofs - 1][:, dofs - 1].tocsc()
+    bs = b[dofs - 1]
+    arrays = hs.serialize_elimtree(sub)
+    sub, sub_loc = hs.symfact(sub)
+    assert len(sub.bnd) > 0
+    F = hs.factor(As, sub, sub_loc, swlevel=0)
+    x = hs.ldiv(F, bs)
+    assert relerr(x, spla.splu(As).solve(bs)) < SOL_TOL
+    o = O.parse_elimtree(*arrays)
+    o, o_loc = O.symfact(o)
+    assert relerr(x, O.ldiv(O.factor(As, o, o_loc, swlevel=0), bs)) < SOL_TOL
+
+
+def test_ldiv_semantics(hs):
+    P = prepare(hs, (20, 20), kind="helmholtz", nmax=30, rhs="randn")
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0)
+    b = P["b"].copy()
+    x2 = hs.ldiv(F, b)  # 2-arg form: returns a new array, b untouched (factornode.jl:62)
+    assert np.array_equal(b, P["b"]) and x2 is not b
+    c = np.empty_like(b)
+    x3 = hs.ldiv(c, F, b)
+    assert x3 is c and np.array_equal(c, x2)
+    hs.ldiv(b, F, b)  # aliasing: true in-place
+    assert np.array_equal(b, x2)
+    # linearity (size-independent property)
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal(len(b)) + 1j * rng.standard_normal(len(b))
+    v = rng.standard_normal(len(b)) + 1j * rng.standard_normal(len(b))
+    lhs = hs.ldiv(F, 2.0 * u - 3.0j * v)
+    assert relerr(lhs, 2.0 * hs.ldiv(F, u) - 3.0j * hs.ldiv(F, v)) < 1e-12
+    with pytest.raises(hs.DimensionMismatch):
+        hs.ldiv(F, b[:-1])
+    assert repr(F) == "FactorNode{ComplexF64}" and F.eltype is np.complex128
+
+
+def test_error_paths_on_device(hs):
+    P = prepare(hs, (9, 9), kind="poisson", nmax=12)
+    with pytest.raises(ValueError, match="swsize"):
+        hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0, swsize=0)
+    with pytest.raises(ValueError, match="c_tol"):
+        hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0, c_tol=0.0)
+    # singular interior block -> SingularException with the node id
+    A = P["A"].tolil(copy=True)
+    leaf = hs.postorder_nodes(P["nd"])[0]
+    i = int(leaf.int[0]) - 1
+    A[:, i] = 0.0
+    A[i, :] = 0.0
+    with pytest.raises(hs.SingularException):
+        hs.factor(A.tocsc(), P["nd"], P["nd_loc"], swlevel=0)
+    # one-child node -> ErrorException (factorization.jl:25)
+    nd = P["nd"]
+    saved = nd.right
+    nd.right = None
+    loc_saved = P["nd_loc"].right
+    P["nd_loc"].right = None
+    with pytest.raises(RuntimeError, match="binary tree"):
+        hs.factor(P["A"], nd, P["nd_loc"], swlevel=0)
+    nd.right, P["nd_loc"].right = saved, loc_saved
+
+
+def test_golden_fixtures_on_device(hs):
+    import glob
+    import os
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert files
+    from test_oracle import load_fixture
+
+    for f in files:
+        fx = load_fixture(f)
+        nd = hs.parse_elimtree(*fx["tree"])
+        nd, nd_loc = hs.symfact(nd)
+        perm = hs.postorder(nd)
+        Ap = fx["A"][perm - 1][:, perm - 1].tocsc()
+        nd = hs.permuted(nd, hs.invperm(perm))
+        F = hs.factor(Ap, nd, nd_loc, swlevel=0, keep_schur=True)
+        x = hs.ldiv(F, fx["b"][perm - 1])
+        assert relerr(x, fx["x"][perm - 1]) < SOL_TOL, f
+        for k in range(F.nnodes):
+            rb = F.reference_blocks(k, with_schur=True)
+            assert relerr(rb["D"], fx["D"][k]) < BLK_TOL, (f, k)
+            if fx["L"][k].size:
+                assert relerr(rb["L"], fx["L"][k]) < BLK_TOL, (f, k)
+                assert relerr(rb["R"], fx["R"][k]) < BLK_TOL, (f, k)
+                assert relerr(rb["S"], fx["S"][k]) < BLK_TOL, (f, k)

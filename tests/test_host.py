@@ -1,0 +1,125 @@
+"""CPU tests of the host logic: symbolic layer vs the oracle's restatement, generators, .mat I/O,
+and that the C-ABI library loads, exports every declared symbol and fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from conftest import ROOT, have_gpu
+from oracle import hs_oracle as O
+
+
+def same_tree(a, b):
+    if (a is None) != (b is None):
+        return False
+    if a is None:
+        return True
+    return np.array_equal(a.int, b.int) and np.array_equal(a.bnd, b.bnd) and same_tree(a.left, b.left) and same_tree(a.right, b.right)
+
+
+@pytest.mark.parametrize("shape,nmax", [((9, 9), 12), ((33, 17), 40), ((6, 6, 6), 30), ((10, 7, 5), 25), ((3, 3), 100)])
+def test_symbolic_layer_matches_oracle(hs, shape, nmax):
+    A, b, nd = hs.problems.make_problem(shape, nmax=nmax)
+    arrays = hs.serialize_elimtree(nd)
+    nd2 = hs.parse_elimtree(*arrays)
+    assert same_tree(nd, nd2)
+    ond = O.parse_elimtree(*arrays)
+    assert same_tree(nd, ond)
+    nd, nd_loc = hs.symfact(nd)
+    ond, ond_loc = O.symfact(ond)
+    assert same_tree(nd, ond) and same_tree(nd_loc, ond_loc)
+    perm = hs.postorder(nd)
+    assert np.array_equal(perm, O.postorder(ond))
+    assert np.array_equal(np.sort(perm), np.arange(1, A.shape[0] + 1))  # every DOF eliminated exactly once
+    nd = hs.permuted(nd, hs.invperm(perm))
+    ond = O.permuted(ond, O.invperm(perm))
+    assert same_tree(nd, ond)
+    for x in hs.postorder_nodes(nd):  # after the postorder permutation every int is a unit range
+        if len(x.int):
+            assert isinstance(hs.contigious(x.int), range)
+    assert hs.depth(nd) == O.depth(ond)
+
+
+def test_generator_sizing_model(hs):
+    """2D h=1/128 -> 511 nodes, depth 9, fronts <= 258."""
+    A, b, nd = hs.problems.make_problem("poisson2d_p1_h128_nmax100")
+    nodes = hs.postorder_nodes(nd)
+    assert A.shape == (16641, 16641) and len(nodes) == 511 and hs.depth(nd) == 9
+    assert max(len(x.int) + len(x.bnd) for x in nodes) == 258
+    # disjoint ownership: leaves partition the DOFs
+    leaves = [x for x in nodes if hs.isleaf(x)]
+    alld = np.sort(np.concatenate([np.concatenate([x.int, x.bnd]) for x in leaves]))
+    assert np.array_equal(alld, np.arange(1, A.shape[0] + 1))
+    Ah, _, _ = hs.problems.make_problem("helmholtz2d_p1_h64_nmax100")
+    assert np.iscomplexobj(Ah.data) and abs(Ah - Ah.T).max() < 1e-14 and abs(Ah - Ah.conj().T).max() > 1e-3  # complex symmetric, non-Hermitian
+
+
+def test_3d_sizing_model(hs):
+    """Poisson 64^3 with leaf <= 4096: top fronts (8192, 0), (3968, 4096) -- the 128^3 model of SURVEY.md 8(d) at half size."""
+    nd = hs.problems.grid_nested_dissection((64, 64, 64), 4096)
+    nodes = hs.postorder_nodes(nd)
+    assert len(nodes) == 127
+    assert (len(nd.int), len(nd.bnd)) == (8192, 0)
+    assert (len(nd.left.int), len(nd.left.bnd)) == (3968, 4096)
+
+
+def test_mat_roundtrip(hs, tmp_path):
+    A, b, nd = hs.problems.make_problem((9, 7), kind="helmholtz", nmax=10, rhs="randn")
+    p = str(tmp_path / "prob.mat")
+    hs.problems.write_problem(p, A, b, nd)
+    A2, b2, nd2 = hs.problems.read_problem(p)
+    assert abs(A - A2).max() == 0 and np.array_equal(b, b2) and same_tree(nd, nd2)
+
+
+def test_parse_elimtree_validation(hs):
+    with pytest.raises(ValueError, match="root"):
+        hs.parse_elimtree([-1, -1], [-1, -1], [-1, -1], [1, 1], np.ones((1, 2)), [0, 0], np.ones((1, 2)))
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        hs.parse_elimtree([-1], [-1, -1], [-1], [1], np.ones((1, 1)), [0], np.ones((1, 1)))
+
+
+def test_options_mirror(hs):
+    o = hs.SolverOptions()
+    assert (o.swlevel, o.swsize, o.atol, o.rtol, o.c_tol, o.leafsize, o.kest, o.stepsize, o.verbose) == (5, 1, 1e-6, 1e-6, 0.5, 32, -1, 10, False)
+    o2 = o.copy(swlevel=-2, atol=1e-2)
+    assert (o2.swlevel, o2.atol, o.swlevel) == (-2, 1e-2, 5)
+    for bad in (dict(swsize=0), dict(atol=-1.0), dict(c_tol=0.0), dict(leafsize=0)):
+        with pytest.raises(ValueError):
+            hs.chkopts(hs.SolverOptions(**bad))
+    with pytest.raises(TypeError):
+        hs.SolverOptions(bogus=1)
+
+
+def test_library_exports_every_declared_symbol(hs):
+    lib = hs._lib.lib()
+    declared = set()
+    for hdr in ("hs_solver.h", "hs_kernels.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        declared |= set(re.findall(r"\b(hsk?_[a-z0-9_]+)\s*\(", txt))
+    assert declared == set(hs._lib.EXPORTS), declared ^ set(hs._lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    # the defaults cross the ABI intact (no GPU needed)
+    o = hs._lib.hs_options()
+    lib.hs_options_default(C.byref(o))
+    assert (o.swlevel, o.swsize, o.atol, o.rtol, o.c_tol, o.leafsize, o.kest, o.stepsize, o.verbose) == (5, 1, 1e-6, 1e-6, 0.5, 32, -1, 10, 0)
+
+
+@pytest.mark.skipif(have_gpu(), reason="checks the no-device failure mode")
+def test_product_path_fails_loudly_without_gpu(hs):
+    A, b, nd = hs.problems.make_problem((9, 9), nmax=12)
+    nd, nd_loc = hs.symfact(nd)
+    with pytest.raises(hs.DeviceError, match="no CPU fallback"):
+        hs.factor(A, nd, nd_loc, swlevel=0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "hierarchicalsolvers.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("the oracle", "").replace("against the oracle", ""), f
