@@ -502,6 +502,7 @@ static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* r
         d.ni1 = x.ni1; d.nb1 = x.nb1;
         d.isleaf = x.leaf ? 1 : 0;
         d.node = id;
+        d.finalize();
         hn.push_back(d);
         flops += (x.level > 0 || true) ? front_flops(x.ni, x.nb) : 0.0;
         for (int side = 0; side < 2; ++side) {

@@ -81,6 +81,17 @@ struct NodeDesc {
   int ni1, nb1;  // branch: sizes of the left child's contribution to int / bnd (front split points); leaf: ni, nb
   int isleaf;
   int node;      // post-order id
+  // the same three matrices indexed by HS_MAT_*: kernels that pick a matrix at run time index these
+  // tables (plain address arithmetic) instead of branching over LF/UR/SB -- hipcc (ROCm 7.2) was seen
+  // to miscompile the three-way scalar select of field addresses ("compiler notes").
+  T* mp[3];
+  int mld[3], mrows[3], mcols[3];
+  __host__ void finalize() {
+    mp[0] = LF; mp[1] = UR; mp[2] = SB;
+    mld[0] = ldl; mld[1] = ldu; mld[2] = lds;
+    mrows[0] = m; mrows[1] = ni; mrows[2] = nb;
+    mcols[0] = ni; mcols[1] = nb; mcols[2] = nb;
+  }
 };
 
 enum { HS_MAT_LF = 0, HS_MAT_UR = 1, HS_MAT_SB = 2 };
@@ -105,14 +116,11 @@ struct GemmProb {
 };
 
 template <class T>
-__device__ inline void mat_of(const NodeDesc<T>& nd, int which, T*& p, int& ld, int& rows, int& cols) {
-  if (which == HS_MAT_LF) {
-    p = nd.LF; ld = nd.ldl; rows = nd.m; cols = nd.ni;
-  } else if (which == HS_MAT_UR) {
-    p = nd.UR; ld = nd.ldu; rows = nd.ni; cols = nd.nb;
-  } else {
-    p = nd.SB; ld = nd.lds; rows = nd.nb; cols = nd.nb;
-  }
+__device__ inline void mat_of(const NodeDesc<T>* pn, int which, T*& p, int& ld, int& rows, int& cols) {
+  p = pn->mp[which];
+  ld = pn->mld[which];
+  rows = pn->mrows[which];
+  cols = pn->mcols[which];
 }
 
 // ---- launch API (implemented in the kernels_*.hip files) -------------------------------------

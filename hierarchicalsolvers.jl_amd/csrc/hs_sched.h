@@ -6,6 +6,8 @@
 // dimension is the width of the finished left half, so almost all flops run at large K.
 #pragma once
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include "../../include/hs_solver.h"
 #include "hs_common.h"
 
@@ -17,6 +19,19 @@ struct Sched {
   hipStream_t s;
   hs_stats* st;
 
+  // HS_DEBUG_SYNC=1: synchronise after every launch and report the first failing one (diagnostics only)
+  void dbg(const char* what, int a = 0, int b = 0, int c = 0, int d = 0) {
+    static int on = -1;
+    if (on < 0) {
+      const char* e = getenv("HS_DEBUG_SYNC");
+      on = (e && (e[0] == '1' || e[0] == '2')) ? 1 : 0;
+    }
+    if (!on) return;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) fprintf(stderr, "[hs debug] %s(%d,%d,%d,%d) nbatch=%d maxni=%d maxnb=%d maxm=%d -> %s\n", what, a, b, c, d, nbatch, maxni, maxnb, maxm, hipGetErrorString(e));
+  }
+
   int rows_of(int mat) const { return mat == HS_MAT_LF ? maxm : (mat == HS_MAT_UR ? maxni : maxnb); }
   int cols_of(int mat) const { return mat == HS_MAT_LF ? maxni : maxnb; }
 
@@ -26,6 +41,7 @@ struct Sched {
     if (M <= 0 || N <= 0 || K <= 0) return;
     launch_gemm_op<T>(dn, nbatch, M, N, op, s);
     st->gemm_launches++;
+    dbg("gemm", cmat, r0, c0, k0);
   }
   void panel(int pb) {
     int c0 = pb * HS_PB;
@@ -33,17 +49,21 @@ struct Sched {
     int cnt = maxni - c0, nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
     for (int round = 0;; ++round) {
       launch_tournament_round<T>(dn, nbatch, pb, round, nch, s);
+      dbg("tournament", pb, round, nch);
       if (nch == 1) break;
       cnt = nch * HS_PB;
       nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
     }
     launch_panel_pivot<T>(dn, nbatch, pb, s);
+    dbg("panel_pivot", pb);
     launch_panel_l21<T>(dn, nbatch, pb, maxm - c0, s);
+    dbg("panel_l21", pb);
   }
   void laswp(int mat, int c0, int c1, int k0, int k1) {
     int nc = std::min(c1, cols_of(mat)) - c0;
     if (nc <= 0 || k0 >= maxni) return;
     launch_laswp<T>(dn, nbatch, mat, c0, c1, k0, k1, nc, s);
+    dbg("laswp", mat, c0, k0, k1);
   }
   // X[r0:r1, c0:c1) <- L[r0:r1, r0:r1]^-1 X
   void trsm_rec(int mat, int r0, int r1, int c0, int c1) {
@@ -52,6 +72,7 @@ struct Sched {
     if (nc <= 0) return;
     if (r1 - r0 == HS_PB) {
       launch_trsm_blk<T>(dn, nbatch, mat, r0, c0, c1, nc, s);
+      dbg("trsm_blk", mat, r0, c0, c1);
       return;
     }
     int mid = (r0 + r1) / 2;

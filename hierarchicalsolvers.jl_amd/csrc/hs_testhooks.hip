@@ -109,6 +109,7 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
     d.ni = (int)ni; d.nb = (int)nb; d.m = m;
     d.ldl = ldl; d.ldu = ldu; d.lds = lds;
     d.ni1 = (int)ni; d.nb1 = (int)nb; d.isleaf = 1; d.node = (int)k;
+    d.finalize();
     const T* Fk = F + (size_t)m * m * k;
     if (ni > 0) CK(hipMemcpy2D(d.LF, sizeof(T) * ldl, Fk, sizeof(T) * m, sizeof(T) * m, ni, hipMemcpyHostToDevice));
     if (ni > 0 && nb > 0) CK(hipMemcpy2D(d.UR, sizeof(T) * ldu, Fk + (size_t)m * ni, sizeof(T) * m, sizeof(T) * ni, nb, hipMemcpyHostToDevice));

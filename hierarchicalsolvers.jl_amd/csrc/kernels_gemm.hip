@@ -19,6 +19,9 @@
 //
 // Complex: planar split when staging (re / im images in LDS), 4 real MFMAs per k-step
 // (re += ar*br - ai*bi, im += ar*bi + ai*br); 128x64 tile, wave tile 64x32.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include "hs_common.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -50,20 +53,22 @@ __device__ inline void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int
 }
 
 template <class T>
-__device__ inline bool resolve_op(const NodeDesc<T>& nd, const GemmOp& op, GemmProb<T>& p) {
+__device__ inline bool resolve_op(const NodeDesc<T>* pn, const GemmOp& op, GemmProb<T>& p) {
   T *cp, *bp;
   int ldc, ldb, crows, ccols, brows, bcols;
-  mat_of(nd, op.cmat, cp, ldc, crows, ccols);
-  mat_of(nd, op.bmat, bp, ldb, brows, bcols);
-  int r1 = min(op.r1, crows), c1 = min(op.c1, ccols), k1 = min(op.k1, nd.ni);
+  mat_of(pn, op.cmat, cp, ldc, crows, ccols);
+  mat_of(pn, op.bmat, bp, ldb, brows, bcols);
+  const int ni = pn->ni, ldl = pn->ldl;
+  T* const LF = pn->LF;
+  int r1 = min(op.r1, crows), c1 = min(op.c1, ccols), k1 = min(op.k1, ni);
   int M = r1 - op.r0, N = c1 - op.c0, K = k1 - op.k0;
   if (M <= 0 || N <= 0 || K <= 0) return false;
-  int aoff = (op.cmat == HS_MAT_SB) ? nd.ni : 0;
-  p.A = nd.LF + (size_t)(op.r0 + aoff) + (size_t)op.k0 * nd.ldl;
+  int aoff = (op.cmat == HS_MAT_SB) ? ni : 0;
+  p.A = LF + (size_t)(op.r0 + aoff) + (size_t)op.k0 * ldl;
   p.B = bp + (size_t)op.k0 + (size_t)op.c0 * ldb;
   p.C = cp + (size_t)op.r0 + (size_t)op.c0 * ldc;
   p.M = M; p.N = N; p.K = K;
-  p.lda = nd.ldl; p.ldb = ldb; p.ldc = ldc;
+  p.lda = ldl; p.ldb = ldb; p.ldc = ldc;
   return true;
 }
 
@@ -353,7 +358,7 @@ template <class T>
 __global__ __launch_bounds__(256, 2) void gemm_op_kernel(const NodeDesc<T>* __restrict__ nodes, GemmOp op) {
   __shared__ double smem[TileCfg<T>::smem_doubles];
   GemmProb<T> p;
-  if (!resolve_op(nodes[blockIdx.y], op, p)) return;
+  if (!resolve_op(nodes + blockIdx.y, op, p)) return;
   gemm_dispatch<T>(p, true, smem);
 }
 
@@ -366,8 +371,44 @@ __global__ __launch_bounds__(256, 2) void gemm_probs_kernel(const GemmProb<T>* _
 }
 
 template <class T>
+__global__ void resolve_dump_kernel(const NodeDesc<T>* __restrict__ nodes, GemmOp op, GemmProb<T>* out, int* ok) {
+  GemmProb<T> p;
+  memset(&p, 0, sizeof p);
+  ok[blockIdx.x] = resolve_op(nodes + blockIdx.x, op, p) ? 1 : 0;
+  out[blockIdx.x] = p;
+}
+
+template <class T>
 void launch_gemm_op(const NodeDesc<T>* dnodes, int nbatch, int maxM, int maxN, const GemmOp& op, hipStream_t s) {
   if (nbatch <= 0 || maxM <= 0 || maxN <= 0) return;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("HS_DEBUG_SYNC");
+      dbg = (e && e[0] == '2') ? 1 : 0;
+    }
+    if (dbg) {  // diagnostics: print what every front resolves this op to (no arithmetic)
+      GemmProb<T>* dp;
+      int* dok;
+      (void)hipMalloc((void**)&dp, sizeof(GemmProb<T>) * nbatch);
+      (void)hipMalloc((void**)&dok, sizeof(int) * nbatch);
+      hipLaunchKernelGGL(resolve_dump_kernel<T>, dim3(nbatch), dim3(1), 0, s, dnodes, op, dp, dok);
+      (void)hipStreamSynchronize(s);
+      GemmProb<T> hp;
+      int hok;
+      NodeDesc<T> hn;
+      for (int i = 0; i < nbatch && i < 4; ++i) {
+        (void)hipMemcpy(&hp, dp + i, sizeof hp, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&hok, dok + i, sizeof hok, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&hn, dnodes + i, sizeof hn, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[hs debug] gemm op c%d b%d r[%d,%d) c[%d,%d) k[%d,%d) node%d: ok=%d A=%p B=%p C=%p M=%d N=%d K=%d ld=%d,%d,%d | LF=%p UR=%p SB=%p ni=%d nb=%d m=%d ld=%d,%d,%d maxM=%d maxN=%d\n",
+                op.cmat, op.bmat, op.r0, op.r1, op.c0, op.c1, op.k0, op.k1, i, hok, (void*)hp.A, (void*)hp.B, (void*)hp.C, hp.M, hp.N, hp.K, hp.lda,
+                hp.ldb, hp.ldc, (void*)hn.LF, (void*)hn.UR, (void*)hn.SB, hn.ni, hn.nb, hn.m, hn.ldl, hn.ldu, hn.lds, maxM, maxN);
+      }
+      (void)hipFree(dp);
+      (void)hipFree(dok);
+    }
+  }
   int tiles = ((maxM + BM - 1) / BM) * ((maxN + TileCfg<T>::bn - 1) / TileCfg<T>::bn);
   hipLaunchKernelGGL(gemm_op_kernel<T>, dim3(tiles, nbatch), dim3(256), 0, s, dnodes, op);
 }

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void laswp_kernel(const NodeDesc<T>* __restric
   const NodeDesc<T> nd = nodes[blockIdx.y];
   T* p;
   int ld, rows, cols;
-  mat_of(nd, mat, p, ld, rows, cols);
+  mat_of(nodes + blockIdx.y, mat, p, ld, rows, cols);
   c1 = min(c1, cols);
   k1 = min(k1, nd.ni);
   const int c = c0 + blockIdx.x * 256 + threadIdx.x;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void trsm_blk_kernel(const NodeDesc<T>* __rest
   if (r0 >= nd.ni) return;
   T* p;
   int ld, rows, cols;
-  mat_of(nd, mat, p, ld, rows, cols);
+  mat_of(nodes + blockIdx.y, mat, p, ld, rows, cols);
   c1 = min(c1, cols);
   if (c0 + (int)blockIdx.x * 256 >= c1) return;
   const int w = min(HS_PB, nd.ni - r0);
