@@ -23,7 +23,7 @@ class hs_options(C.Structure):
     _fields_ = [
         ("swlevel", i64), ("swsize", i64), ("atol", C.c_double), ("rtol", C.c_double), ("c_tol", C.c_double),
         ("leafsize", i64), ("kest", i64), ("stepsize", i64), ("verbose", C.c_uint8),
-        ("keep_schur", C.c_uint8), ("reserved", C.c_uint8 * 6), ("seed", i64),
+        ("keep_schur", C.c_uint8), ("profile", C.c_uint8), ("reserved", C.c_uint8 * 5), ("seed", i64),
     ]
 
 
@@ -55,6 +55,9 @@ EXPORTS = [
     "hs_options_default", "hs_factor_d", "hs_factor_z", "hs_ldiv_d", "hs_ldiv_z", "hs_ldiv_dev_d", "hs_ldiv_dev_z",
     "hs_maxrank", "hs_is_complex", "hs_size", "hs_free", "hs_last_error", "hs_last_error_info", "hs_get_stats",
     "hs_node_info", "hs_node_export", "hs_node_export_piv", "hs_device_info",
+    "hs_analyze", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
+    "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
+    "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak",
 ]
 
@@ -94,6 +97,32 @@ def lib():
     for f in (L.hs_ldiv_dev_d, L.hs_ldiv_dev_z):
         f.argtypes = [vp, vp, i64, vp, i64, i64, i64, vp]
         f.restype = C.c_int
+    L.hs_analyze.argtypes = [C.c_int, i64, p_i64, p_i64, C.POINTER(hs_tree), C.POINTER(hs_options), i64, i64, C.POINTER(vp)]
+    L.hs_analyze.restype = C.c_int
+    L.hs_numeric_begin.argtypes = [vp, vp, C.c_int]
+    L.hs_numeric_begin.restype = C.c_int
+    L.hs_numeric_levels.argtypes = [vp, i64, i64]
+    L.hs_numeric_levels.restype = C.c_int
+    L.hs_numeric_end.argtypes = [vp]
+    L.hs_numeric_end.restype = C.c_int
+    for f in (L.hs_solve_fwd_levels, L.hs_solve_bwd_levels):
+        f.argtypes = [vp, vp, i64, i64, vp]
+        f.restype = C.c_int
+    for f in (L.hs_nlevels, L.hs_cut_level, L.hs_num_exchanges):
+        f.argtypes = [vp]
+        f.restype = i64
+    L.hs_node_owner.argtypes = [vp, i64]
+    L.hs_node_owner.restype = i64
+    L.hs_exchange_info.argtypes = [vp, i64, p_i64]
+    L.hs_exchange_info.restype = C.c_int
+    L.hs_set_schur_buffer.argtypes = [vp, i64, vp]
+    L.hs_set_schur_buffer.restype = C.c_int
+    L.hs_pack_bnd.argtypes = [vp, i64, vp, vp, vp]
+    L.hs_pack_bnd.restype = C.c_int
+    L.hs_unpack_bnd.argtypes = [vp, i64, vp, vp, vp]
+    L.hs_unpack_bnd.restype = C.c_int
+    L.hs_extract_owned.argtypes = [vp, vp, vp, vp]
+    L.hs_extract_owned.restype = C.c_int
     L.hs_maxrank.argtypes = [vp]
     L.hs_maxrank.restype = i64
     L.hs_is_complex.argtypes = [vp]

@@ -5,7 +5,15 @@
 // Reference control flow being replaced: factor/_factor recursion (src/factorization.jl:5-27),
 // _factor_leaf / _factor_branch dense variants (:30-42, :62-75), ldiv! (src/factornode.jl:62-99).
 // The reference walks the tree sequentially (left subtree, then right, :20-21); here every node of
-// one tree level is processed by the same grouped kernel launches (blockIdx.y = node).
+// one tree level is processed by the same grouped kernel launches (blockIdx.y = node), and with
+// nranks > 1 the subtrees below the cut level belong to different ranks (one process per GPU).
+//
+// Phases (hs_factor_* = analyze + numeric over all levels):
+//   hs_analyze        plan, HBM allocation, upload of the sparsity pattern / index lists / descriptors
+//   hs_numeric_begin  values of A (host or device pointer) -> device
+//   hs_numeric_levels assemble + eliminate the owned fronts of a range of tree levels
+//   hs_numeric_end    synchronise, singular-front check, timings
+//   hs_solve_*_levels forward / backward sweeps over a range of levels on a device vector
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -36,11 +44,24 @@ void hs_set_error(int code, long long info, const char* fmt, ...) {
 struct HsError {
   int code;
 };
-#define HS_FAIL(code, info, ...)         \
-  do {                                   \
+#define HS_FAIL(code, info, ...)           \
+  do {                                     \
     hs_set_error(code, info, __VA_ARGS__); \
-    throw HsError{code};                 \
+    throw HsError{code};                   \
   } while (0)
+
+#define HS_GUARD(...)                                        \
+  try {                                                      \
+    __VA_ARGS__;                                             \
+    return HS_OK;                                            \
+  } catch (const HsError& e) {                               \
+    return e.code;                                           \
+  } catch (int code) {                                       \
+    return code;                                             \
+  } catch (const std::bad_alloc&) {                          \
+    hs_set_error(HS_ERR_NOMEM, 0, "host allocation failed"); \
+    return HS_ERR_NOMEM;                                     \
+  }
 
 extern "C" const char* hs_last_error(void) { return g_err.c_str(); }
 extern "C" int64_t hs_last_error_info(void) { return g_err_info; }
@@ -83,75 +104,87 @@ struct NodeH {
   int ni = 0, nb = 0, m = 0;
   int ni1 = 0, nb1 = 0;
   bool leaf = true;
+  int owner = 0;       // rank that eliminates this front
+  bool mine = true;    // owner == my rank
+  bool ghost = false;  // not mine, but one of my fronts absorbs its Schur complement (received from its owner)
   int ldl = 0, ldu = 0, lds = 0;
-  size_t off_LF = 0, off_UR = 0, off_SB = 0, off_inv = 0;  // element offsets
+  size_t off_LF = 0, off_UR = 0, off_SB = 0, off_inv = 0;                        // element offsets
   size_t off_fidx = 0, off_ipiv = 0, off_rperm = 0, off_cmap = 0, off_cand = 0;  // int offsets
   int ncand = 0;
-  int batch_pos = 0;  // index inside its level batch
+  int batch_pos = -1;      // index inside its level's batch of owned fronts
+  void* ext_sb = nullptr;  // caller-provided device buffer for the Schur complement (exchange between ranks)
+  long long woff = 0;
 };
 
 struct LevelH {
-  std::vector<int> nodes;
-  int maxni = 0, maxnb = 0, maxm = 0;
-  size_t lf_begin = 0, lf_end = 0;  // factor-arena range (elements) holding this level's LF/UR
+  std::vector<int> nodes;  // every node of the level
+  std::vector<int> mine;   // nodes this rank eliminates
+  int maxni = 0, maxnb = 0, maxm = 0, maxnbc = 0;
+  size_t lf_begin = 0, lf_end = 0;  // factor-arena range (elements) of this level's LF/UR
   size_t sb_begin = 0, sb_end = 0;  // SB range (elements)
-  size_t solve_off = 0;             // first SolveNode of this level
+  size_t desc_off = 0;              // first NodeDesc / SolveNode of this level (owned fronts only)
+  size_t sc_off = 0, sc_cnt = 0;    // ScatterDesc range
+  std::vector<int> h_ni, h_nb;
 };
+
+struct Exchange {
+  int node, level, src, dst, nb;
+  long long nelems;
+};
+
+#include "hs_sched.h"
 
 struct hs_handle {
   bool is_complex = false;
-  int64_t n = 0;
+  int64_t n = 0, nnz = 0;
   int nnodes = 0;  // tree nodes (+1 pseudo-node when the root keeps a boundary)
   int nreal = 0;
+  int rank = 0, nranks = 1, cut_level = 1;  // levels > cut_level are rank-local
   hs_options opts;
   std::vector<NodeH> nodes;
-  std::vector<LevelH> levels;  // index = level, processed from back (deepest) to front
-  std::vector<int> fidx_host;  // concatenated front index lists
+  std::vector<LevelH> levels;  // index = level (0 = pseudo-root)
+  std::vector<int> fidx_host;
+  std::vector<Exchange> exchanges;
   // device
-  void* d_fac = nullptr;   // LF / UR
-  void* d_inv = nullptr;   // invL / invU
-  void* d_sb = nullptr;    // SB scratch (or permanent with keep_schur)
-  int* d_int = nullptr;    // fidx, ipiv, rperm, cmap
-  int* d_tmpi = nullptr;   // cand, pivlist, info, own, pos
-  void* d_solve = nullptr; // SolveNode array
+  void* d_fac = nullptr;  // LF / UR
+  void* d_inv = nullptr;  // invL / invU
+  void* d_sb = nullptr;   // SB scratch (or permanent with keep_schur)
+  int* d_int = nullptr;   // fidx, ipiv, rperm, cmap
+  int* d_tmpi = nullptr;  // cand, pivlist, info[nnodes], own[n], pos[n]
+  int* d_info = nullptr;
+  int* d_own = nullptr;
+  int* d_pos = nullptr;
+  int64_t* d_colptr = nullptr;
+  int32_t* d_rowval = nullptr;
+  void* d_nz = nullptr;
+  void* d_nodes = nullptr;  // NodeDesc<T>[] of the owned fronts, level by level
+  void* d_sc = nullptr;     // ScatterDesc<T>[]
+  void* d_solve = nullptr;  // SolveNode<T>[] (same order as d_nodes)
   void* d_w1 = nullptr;
   void* d_w2 = nullptr;
   void* d_part = nullptr;
   void* d_b = nullptr;
-  size_t fac_elems = 0, inv_elems = 0, sb_elems = 0, int_elems = 0, part_elems = 0;
+  size_t fac_elems = 0, inv_elems = 0, sb_elems = 0, int_elems = 0;
   bool sb_kept = false;
+  bool numeric_open = false, factored = false;
   hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  Profiler prof;
+  double flops = 0.0;
   hs_stats stats;
 };
 
 static inline int rup(int x, int a) { return (x + a - 1) / a * a; }
 static inline size_t rups(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  void alloc(size_t n) {
-    if (n == 0) n = 1;
-    if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) {
-      p = nullptr;
-      HS_FAIL(HS_ERR_NOMEM, 0, "hipMalloc of %zu bytes failed", n * sizeof(T));
-    }
-  }
-  T* release() {
-    T* q = p;
-    p = nullptr;
-    return q;
-  }
-};
-
 static void free_handle(hs_handle* h) {
   if (!h) return;
-  void* ptrs[] = {h->d_fac, h->d_inv, h->d_sb, h->d_int, h->d_tmpi, h->d_solve, h->d_w1, h->d_w2, h->d_part, h->d_b};
+  void* ptrs[] = {h->d_fac,   h->d_inv, h->d_sb,    h->d_int, h->d_tmpi, h->d_colptr, h->d_rowval, h->d_nz,
+                  h->d_nodes, h->d_sc,  h->d_solve, h->d_w1,  h->d_w2,   h->d_part,   h->d_b};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -186,8 +219,7 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
   }
   for (int i = 0; i < nn - 1; ++i)
     if (N[i].parent < 0) HS_FAIL(HS_ERR_ARGUMENT, i, "ArgumentError: found either less than or more than one root.");
-  // levels: root = 1
-  N[nn - 1].level = 1;
+  N[nn - 1].level = 1;  // levels: root = 1
   int maxlevel = 1;
   for (int i = nn - 2; i >= 0; --i) {
     N[i].level = N[N[i].parent].level + 1;
@@ -222,7 +254,7 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
     for (int side = 0; side < 2; ++side) {
       int c = side == 0 ? x.left : x.right;
       const NodeH& ch = N[c];
-      const int* cb = &F[ch.off_fidx + ch.ni];
+      const int* cb = F.data() + ch.off_fidx + ch.ni;
       for (int64_t e = tr->iloc_ptr[c]; e < tr->iloc_ptr[c + 1]; ++e, ++pi) {
         int64_t q = tr->iloc_idx[e];
         if (q < 1 || q > ch.nb) HS_FAIL(HS_ERR_DIMENSION, c, "BoundsError: nd_loc.int position %lld outside child bnd 1:%d", (long long)q, ch.nb);
@@ -243,8 +275,8 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
     if (pi != x.ni || pb != x.nb)
       HS_FAIL(HS_ERR_DIMENSION, i, "DimensionMismatch: children contribute (%d,%d) DOFs, node %d has (%d,%d)", pi, pb, i, x.ni, x.nb);
   }
-  // every DOF must be eliminated at most once; fronts of unrelated nodes must be disjoint (the
-  // reference concatenates child Schur complements, it never extend-adds: factorization.jl:118-121)
+  // every DOF is eliminated at most once; the reference concatenates child Schur complements, it
+  // never extend-adds (factorization.jl:118-121), so fronts of unrelated nodes are disjoint
   {
     std::vector<char> seen(n, 0);
     for (int i = 0; i < nn; ++i)
@@ -256,7 +288,6 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
   }
   // pseudo-node: the root's own boundary (normally empty) is eliminated last, `F.S \ C[F.bnd,:]` (factornode.jl:72)
   const NodeH root = N[nn - 1];
-  int lvl0 = 1;
   if (root.nb > 0) {
     NodeH r;
     r.leaf = false;
@@ -272,39 +303,87 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
     for (int e = 0; e < root.nb; ++e) F.push_back(F[root.off_fidx + root.ni + e]);
     N.push_back(r);
     N[nn - 1].parent = nn;
-    lvl0 = 0;
   }
   h->nnodes = (int)N.size();
   h->levels.assign(maxlevel + 1, LevelH());
+
+  // ---- ownership: the 2^p subtrees rooted at level p+1 go one per rank; a node above the cut is
+  // eliminated by the first rank of the group that owns the subtrees below it.
+  int p = 0;
+  while ((1 << (p + 1)) <= h->nranks) ++p;
+  if ((1 << p) != h->nranks) HS_FAIL(HS_ERR_ARGUMENT, h->nranks, "ArgumentError: nranks = %d must be a power of two", h->nranks);
+  h->cut_level = p + 1;
+  {
+    std::vector<int> lo(h->nnodes, 0), cnt(h->nnodes, h->nranks);  // rank range [lo, lo+cnt) below each node
+    for (int i = h->nnodes - 1; i >= 0; --i) {
+      NodeH& x = N[i];
+      if (x.level == 0) {  // pseudo-root: same owner as the root
+        lo[x.left] = 0;
+        cnt[x.left] = h->nranks;
+      }
+      x.owner = lo[i];
+      x.mine = (x.owner == h->rank);
+      if (!x.leaf && x.level >= 1) {
+        if (cnt[i] > 1) {
+          lo[x.left] = lo[i];
+          cnt[x.left] = cnt[i] / 2;
+          lo[x.right] = lo[i] + cnt[i] / 2;
+          cnt[x.right] = cnt[i] / 2;
+        } else {
+          lo[x.left] = lo[x.right] = lo[i];
+          cnt[x.left] = cnt[x.right] = 1;
+        }
+      }
+    }
+  }
+  h->exchanges.clear();
+  for (int i = 0; i < h->nnodes; ++i) {
+    NodeH& x = N[i];
+    if (x.parent >= 0 && N[x.parent].owner != x.owner) {
+      h->exchanges.push_back({i, x.level, x.owner, N[x.parent].owner, x.nb, 0});
+      if (N[x.parent].mine) x.ghost = true;
+    }
+  }
   for (int i = 0; i < h->nnodes; ++i) {
     LevelH& L = h->levels[N[i].level];
-    N[i].batch_pos = (int)L.nodes.size();
     L.nodes.push_back(i);
+    if (!N[i].mine) continue;
+    N[i].batch_pos = (int)L.mine.size();
+    L.mine.push_back(i);
+    L.h_ni.push_back(N[i].ni);
+    L.h_nb.push_back(N[i].nb);
     L.maxni = std::max(L.maxni, N[i].ni);
     L.maxnb = std::max(L.maxnb, N[i].nb);
     L.maxm = std::max(L.maxm, N[i].m);
   }
-  (void)lvl0;
 }
 
 static double front_flops(double ni, double nb) { return (2.0 / 3.0) * ni * ni * ni + 2.0 * ni * ni * nb + 2.0 * ni * nb * nb; }
 
-#include "hs_sched.h"
+static void dmalloc(void** p, size_t bytes, const char* what) {
+  if (bytes == 0) bytes = 256;
+  if (hipMalloc(p, bytes) != hipSuccess) {
+    *p = nullptr;
+    (void)hipGetLastError();
+    HS_FAIL(HS_ERR_NOMEM, 0, "hipMalloc of %.3f GiB for %s failed", bytes / 1073741824.0, what);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
-// factor
+// analyze
 // ------------------------------------------------------------------------------------------------
 template <class T>
-static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* rowval, const T* nzval, const hs_tree* tree,
-                              const hs_options* opts_in) {
+static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* rowval, const hs_tree* tree, const hs_options* opts_in,
+                               int rank, int nranks) {
   hs_options opts;
   if (opts_in)
     opts = *opts_in;
   else
     hs_options_default(&opts);
   chkopts(opts);
-  if (n <= 0 || !colptr || !rowval || !nzval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: empty matrix");
+  if (n <= 0 || !colptr || !rowval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: empty matrix");
   if (colptr[0] != 1) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: colptr must be 1-based (SparseMatrixCSC)");
+  if (nranks < 1 || rank < 0 || rank >= nranks) HS_FAIL(HS_ERR_ARGUMENT, rank, "ArgumentError: rank %d of %d", rank, nranks);
   require_device();
 
   hs_handle* h = new hs_handle();
@@ -312,6 +391,8 @@ static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* r
     h->is_complex = sizeof(T) == 16;
     h->n = n;
     h->opts = opts;
+    h->rank = rank;
+    h->nranks = nranks;
     memset(&h->stats, 0, sizeof h->stats);
     build_plan(h, n, tree);
     std::vector<NodeH>& N = h->nodes;
@@ -327,19 +408,30 @@ static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* r
                 i, N[i].level, (long long)swlevel, N[i].nb, (long long)opts.swsize);
     }
 
-    // ---- HBM layout ----------------------------------------------------------------------------
+    // ---- HBM layout (owned fronts: LF/UR/inv; owned + ghost fronts: SB) ------------------------------
     size_t fac = 0, inv = 0, ints = h->fidx_host.size(), tmpi = 0;
     size_t sbpar[2] = {0, 0};
     std::vector<size_t> sb_level_size(h->levels.size(), 0);
+    long long woff = 0, poff = 0;
+    size_t ndesc = 0;
     for (int lv = (int)h->levels.size() - 1; lv >= 0; --lv) {
       LevelH& L = h->levels[lv];
       L.lf_begin = fac;
+      L.desc_off = ndesc;
+      ndesc += L.mine.size();
       size_t sb = 0;
       for (int id : L.nodes) {
         NodeH& x = N[id];
         x.ldl = rup(std::max(x.m, 1), 2);
         x.ldu = rup(std::max(x.ni, 1), 2);
         x.lds = rup(std::max(x.nb, 1), 2);
+        if (x.mine || x.ghost) {
+          x.off_SB = sb;
+          sb += rups((size_t)x.lds * x.nb, 32);
+          x.off_cmap = ints;
+          ints += x.nb;
+        }
+        if (!x.mine) continue;
         x.off_LF = fac;
         fac += rups((size_t)x.ldl * x.ni, 32);
         x.off_UR = fac;
@@ -347,17 +439,15 @@ static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* r
         int nblk = (x.ni + HS_PB - 1) / HS_PB;
         x.off_inv = inv;
         inv += (size_t)2 * nblk * HS_PB * HS_PB;
-        x.off_SB = sb;
-        sb += rups((size_t)x.lds * x.nb, 32);
         x.off_ipiv = ints;
         ints += x.ni;
         x.off_rperm = ints;
         ints += x.ni;
-        x.off_cmap = ints;
-        ints += x.nb;
         x.ncand = ((x.ni + HS_CHUNK - 1) / HS_CHUNK + 1) * HS_PB;
         x.off_cand = tmpi;
-        tmpi += (size_t)2 * x.ncand + HS_PB + 1;
+        tmpi += (size_t)2 * x.ncand + HS_PB;
+        x.woff = woff;
+        woff += x.ni;
       }
       L.lf_end = fac;
       sb_level_size[lv] = sb;
@@ -379,48 +469,38 @@ static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* r
       }
     }
     for (int lv = 0; lv < (int)h->levels.size(); ++lv)
-      for (int id : h->levels[lv].nodes) N[id].off_SB += h->levels[lv].sb_begin;
+      for (int id : h->levels[lv].nodes)
+        if (N[id].mine || N[id].ghost) N[id].off_SB += h->levels[lv].sb_begin;
+    for (auto& ex : h->exchanges) ex.nelems = (long long)N[ex.node].lds * N[ex.node].nb;
     h->fac_elems = fac;
     h->inv_elems = inv;
     h->sb_elems = sb_total;
     h->int_elems = ints;
 
     HS_HIP(hipStreamCreate(&h->stream));
-    hipStream_t s = h->stream;
-    hipEvent_t ev0, ev1;
-    HS_HIP(hipEventCreate(&ev0));
-    HS_HIP(hipEventCreate(&ev1));
-
-    auto dmalloc = [&](void** p, size_t bytes) {
-      if (bytes == 0) bytes = 256;
-      if (hipMalloc(p, bytes) != hipSuccess) {
-        *p = nullptr;
-        HS_FAIL(HS_ERR_NOMEM, 0, "hipMalloc of %.3f GiB failed (factors need %.3f GiB)", bytes / 1073741824.0,
-                (fac + inv) * sizeof(T) / 1073741824.0);
-      }
-    };
-    dmalloc(&h->d_fac, fac * sizeof(T));
-    dmalloc(&h->d_inv, inv * sizeof(T));
-    dmalloc(&h->d_sb, sb_total * sizeof(T));
-    dmalloc((void**)&h->d_int, ints * sizeof(int));
-    const size_t tmpi_total = tmpi + 2 * (size_t)n;
-    dmalloc((void**)&h->d_tmpi, tmpi_total * sizeof(int));
+    HS_HIP(hipEventCreate(&h->ev0));
+    HS_HIP(hipEventCreate(&h->ev1));
+    dmalloc(&h->d_fac, fac * sizeof(T), "the factors (LF/UR)");
+    dmalloc(&h->d_inv, inv * sizeof(T), "the inverse diagonal blocks");
+    dmalloc(&h->d_sb, sb_total * sizeof(T), "the Schur-complement scratch");
+    dmalloc((void**)&h->d_int, ints * sizeof(int), "index lists");
+    const size_t tmpi_total = tmpi + (size_t)h->nnodes + 2 * (size_t)n;
+    dmalloc((void**)&h->d_tmpi, tmpi_total * sizeof(int), "pivoting scratch");
+    HS_HIP(hipMemset(h->d_tmpi, 0, tmpi_total * sizeof(int)));
+    h->d_info = h->d_tmpi + tmpi;
+    h->d_own = h->d_info + h->nnodes;
+    h->d_pos = h->d_own + n;
     T* dfac = (T*)h->d_fac;
     T* dinv = (T*)h->d_inv;
     T* dsb = (T*)h->d_sb;
     int* dint = h->d_int;
-    int* dtmp = h->d_tmpi;
-    int* d_own = dtmp + tmpi;
-    int* d_pos = d_own + n;
 
-    // ---- upload A (0-based), index lists, cmaps ---------------------------------------------------
+    // ---- sparsity pattern of A (0-based), index lists, cmaps -------------------------------------------
     const int64_t nnz = colptr[n] - 1;
-    DevBuf<int64_t> d_colptr;
-    DevBuf<int32_t> d_rowval;
-    DevBuf<T> d_nz;
-    d_colptr.alloc(n + 1);
-    d_rowval.alloc(nnz);
-    d_nz.alloc(nnz);
+    h->nnz = nnz;
+    dmalloc((void**)&h->d_colptr, (n + 1) * sizeof(int64_t), "colptr");
+    dmalloc((void**)&h->d_rowval, nnz * sizeof(int32_t), "rowval");
+    dmalloc(&h->d_nz, nnz * sizeof(T), "nzval");
     {
       std::vector<int64_t> cp(n + 1);
       for (int64_t j = 0; j <= n; ++j) {
@@ -433,9 +513,8 @@ static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* r
         if (r < 1 || r > n) HS_FAIL(HS_ERR_DIMENSION, e, "BoundsError: rowval[%lld] = %lld outside 1:%lld", (long long)e + 1, (long long)r, (long long)n);
         rv[e] = (int32_t)(r - 1);
       }
-      HS_HIP(hipMemcpy(d_colptr.p, cp.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-      HS_HIP(hipMemcpy(d_rowval.p, rv.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-      HS_HIP(hipMemcpy(d_nz.p, nzval, nnz * sizeof(T), hipMemcpyHostToDevice));
+      HS_HIP(hipMemcpy(h->d_colptr, cp.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+      HS_HIP(hipMemcpy(h->d_rowval, rv.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     {
       std::vector<int> hint(ints, 0);
@@ -443,8 +522,8 @@ static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* r
       // cmap of every non-root node: position of each of its bnd DOFs in the parent's front
       for (int i = 0; i < h->nnodes; ++i) {
         NodeH& x = N[i];
-        if (x.parent < 0) continue;
-        int* cm = &hint[x.off_cmap];
+        if (x.parent < 0 || !(x.mine || x.ghost)) continue;
+        int* cm = hint.data() + x.off_cmap;
         for (int e = 0; e < x.nb; ++e) cm[e] = -1;
         const NodeH& p = N[x.parent];
         if (p.level == 0) {  // pseudo-root: identity
@@ -460,167 +539,90 @@ static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* r
       }
       HS_HIP(hipMemcpy(dint, hint.data(), ints * sizeof(int), hipMemcpyHostToDevice));
     }
-    HS_HIP(hipMemsetAsync(dtmp, 0, tmpi * sizeof(int), s));
-    HS_HIP(hipMemsetAsync(d_own, 0xff, n * sizeof(int), s));
 
-    // ---- levels, deepest first -------------------------------------------------------------------
-    size_t maxbatch = 0;
-    for (auto& L : h->levels) maxbatch = std::max(maxbatch, L.nodes.size());
-    DevBuf<NodeDesc<T>> d_nodes;
-    d_nodes.alloc(maxbatch);
-    DevBuf<ScatterDesc<T>> d_sc;
-    d_sc.alloc(2 * maxbatch);
-    std::vector<NodeDesc<T>> hn;
-    std::vector<ScatterDesc<T>> hsc;
-
-    HS_HIP(hipEventRecord(ev0, s));
-    double flops = 0.0;
-    for (int lv = (int)h->levels.size() - 1; lv >= 0; --lv) {
-      LevelH& L = h->levels[lv];
-      if (L.nodes.empty()) continue;
-      hn.clear();
-      hsc.clear();
-      int maxnbc = 0;
-      for (int id : L.nodes) {
-        NodeH& x = N[id];
-        NodeDesc<T> d;
-        memset(&d, 0, sizeof d);
-        d.LF = dfac + x.off_LF;
-        d.UR = dfac + x.off_UR;
-        d.SB = dsb + x.off_SB;
-        int nblk = (x.ni + HS_PB - 1) / HS_PB;
-        d.invL = dinv + x.off_inv;
-        d.invU = dinv + x.off_inv + (size_t)nblk * HS_PB * HS_PB;
-        d.ipiv = dint + x.off_ipiv;
-        d.cand0 = dtmp + x.off_cand;
-        d.cand1 = d.cand0 + x.ncand;
-        d.pivlist = d.cand1 + x.ncand;
-        d.info = d.pivlist + HS_PB;
-        d.fidx = dint + x.off_fidx;
-        d.ni = x.ni; d.nb = x.nb; d.m = x.m;
-        d.ldl = x.ldl; d.ldu = x.ldu; d.lds = x.lds;
-        d.ni1 = x.ni1; d.nb1 = x.nb1;
-        d.isleaf = x.leaf ? 1 : 0;
-        d.node = id;
-        d.finalize();
-        hn.push_back(d);
-        flops += (x.level > 0 || true) ? front_flops(x.ni, x.nb) : 0.0;
-        for (int side = 0; side < 2; ++side) {
-          int c = side == 0 ? x.left : x.right;
-          if (x.leaf || c < 0) continue;
-          const NodeH& ch = N[c];
-          if (ch.nb == 0) continue;
-          ScatterDesc<T> sc;
-          sc.S = dsb + ch.off_SB;
-          sc.cmap = dint + ch.off_cmap;
-          sc.nbc = ch.nb;
-          sc.lds = ch.lds;
-          sc.parent = x.batch_pos;
-          hsc.push_back(sc);
-          maxnbc = std::max(maxnbc, ch.nb);
-        }
-      }
-      const int nb_ = (int)hn.size();
-      HS_HIP(hipMemcpyAsync(d_nodes.p, hn.data(), nb_ * sizeof(NodeDesc<T>), hipMemcpyHostToDevice, s));
-      if (!hsc.empty()) HS_HIP(hipMemcpyAsync(d_sc.p, hsc.data(), hsc.size() * sizeof(ScatterDesc<T>), hipMemcpyHostToDevice, s));
-      HS_HIP(hipStreamSynchronize(s));  // hn/hsc are reused by the next level
-      // zero-fill this level's fronts
-      if (L.lf_end > L.lf_begin) HS_HIP(hipMemsetAsync(dfac + L.lf_begin, 0, (L.lf_end - L.lf_begin) * sizeof(T), s));
-      if (L.sb_end > L.sb_begin) HS_HIP(hipMemsetAsync(dsb + L.sb_begin, 0, (L.sb_end - L.sb_begin) * sizeof(T), s));
-      launch_mark<T>(d_nodes.p, nb_, L.maxm, d_own, d_pos, s);
-      launch_gather<T>(d_nodes.p, nb_, L.maxm, d_colptr.p, d_rowval.p, d_nz.p, d_own, d_pos, s);
-      launch_scatter<T>(d_nodes.p, d_sc.p, (int)hsc.size(), maxnbc, s);
-      Sched<T> sch{d_nodes.p, nb_, L.maxni, L.maxnb, L.maxm, s, &h->stats};
-      sch.factor_fronts();
-    }
-    HS_HIP(hipEventRecord(ev1, s));
-    HS_HIP(hipStreamSynchronize(s));
-    float ms = 0.f;
-    HS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    h->stats.t_total = ms * 1e-3;
-
-    // ---- singular fronts, row permutations ---------------------------------------------------------
+    // ---- device descriptors (built once; pointers are fixed from here on) ------------------------------------
     {
-      std::vector<int> htmp(tmpi);
-      HS_HIP(hipMemcpy(htmp.data(), dtmp, tmpi * sizeof(int), hipMemcpyDeviceToHost));
-      for (int i = 0; i < h->nnodes; ++i) {
-        int info = htmp[N[i].off_cand + 2 * N[i].ncand + HS_PB];
-        if (info != 0)
-          HS_FAIL(HS_ERR_SINGULAR, i, "SingularException(%d): exactly zero pivot in the interior block of node %d (ni=%d, nb=%d)", info,
-                  i, N[i].ni, N[i].nb);
-      }
-      std::vector<int> hint(ints);
-      HS_HIP(hipMemcpy(hint.data(), dint, ints * sizeof(int), hipMemcpyDeviceToHost));
-      for (int i = 0; i < h->nnodes; ++i) {
-        const NodeH& x = N[i];
-        int* ip = &hint[x.off_ipiv];
-        int* rp = &hint[x.off_rperm];
-        for (int k = 0; k < x.ni; ++k) rp[k] = k;
-        for (int k = 0; k < x.ni; ++k) {
-          int p = ip[k];
-          if (p < 0 || p >= x.ni) HS_FAIL(HS_ERR_DEVICE, i, "internal error: pivot %d of node %d out of range", p, i);
-          std::swap(rp[k], rp[p]);
-        }
-      }
-      HS_HIP(hipMemcpy(dint, hint.data(), ints * sizeof(int), hipMemcpyHostToDevice));
-    }
-    // scratch no longer needed
-    (void)hipFree(h->d_tmpi);
-    h->d_tmpi = nullptr;
-    if (!opts.keep_schur) {
-      (void)hipFree(h->d_sb);
-      h->d_sb = nullptr;
-    }
-
-    // ---- solve descriptors -----------------------------------------------------------------------------
-    {
+      std::vector<NodeDesc<T>> hn;
+      std::vector<ScatterDesc<T>> hsc;
       std::vector<SolveNode<T>> sn;
-      long long woff = 0, poff = 0;
-      for (int lv = 0; lv < (int)h->levels.size(); ++lv) {
+      for (int lv = (int)h->levels.size() - 1; lv >= 0; --lv) {
         LevelH& L = h->levels[lv];
-        L.solve_off = sn.size();
-        for (int id : L.nodes) {
-          const NodeH& x = N[id];
+        L.sc_off = hsc.size();
+        for (int id : L.mine) {
+          NodeH& x = N[id];
+          NodeDesc<T> d;
+          memset(&d, 0, sizeof d);
+          d.LF = dfac + x.off_LF;
+          d.UR = dfac + x.off_UR;
+          d.SB = dsb + x.off_SB;
+          int nblk = (x.ni + HS_PB - 1) / HS_PB;
+          d.invL = dinv + x.off_inv;
+          d.invU = dinv + x.off_inv + (size_t)nblk * HS_PB * HS_PB;
+          d.ipiv = dint + x.off_ipiv;
+          d.rperm = dint + x.off_rperm;
+          d.cand0 = h->d_tmpi + x.off_cand;
+          d.cand1 = d.cand0 + x.ncand;
+          d.pivlist = d.cand1 + x.ncand;
+          d.info = h->d_info + id;
+          d.fidx = dint + x.off_fidx;
+          d.ni = x.ni; d.nb = x.nb; d.m = x.m;
+          d.ldl = x.ldl; d.ldu = x.ldu; d.lds = x.lds;
+          d.ni1 = x.ni1; d.nb1 = x.nb1;
+          d.isleaf = x.leaf ? 1 : 0;
+          d.node = id;
+          d.finalize();
+          hn.push_back(d);
           SolveNode<T> q;
           memset(&q, 0, sizeof q);
-          q.LF = dfac + x.off_LF;
-          q.UR = dfac + x.off_UR;
-          int nblk = (x.ni + HS_PB - 1) / HS_PB;
-          q.invL = dinv + x.off_inv;
-          q.invU = dinv + x.off_inv + (size_t)nblk * HS_PB * HS_PB;
-          q.rperm = dint + x.off_rperm;
-          q.fidx = dint + x.off_fidx;
+          q.LF = d.LF; q.UR = d.UR; q.invL = d.invL; q.invU = d.invU;
+          q.rperm = d.rperm; q.fidx = d.fidx;
           q.ni = x.ni; q.nb = x.nb; q.m = x.m; q.ldl = x.ldl; q.ldu = x.ldu;
-          q.woff = woff;
+          q.woff = x.woff;
           q.poff = poff;
-          woff += x.ni;
           poff += (long long)((x.nb + 511) / 512) * x.ni;
           sn.push_back(q);
+          h->flops += front_flops(x.ni, x.nb);
+          for (int side = 0; side < 2; ++side) {
+            int c = side == 0 ? x.left : x.right;
+            if (x.leaf || c < 0) continue;
+            const NodeH& ch = N[c];
+            if (ch.nb == 0) continue;
+            ScatterDesc<T> sc;
+            sc.S = dsb + ch.off_SB;
+            sc.cmap = dint + ch.off_cmap;
+            sc.nbc = ch.nb;
+            sc.lds = ch.lds;
+            sc.parent = x.batch_pos;
+            hsc.push_back(sc);
+            L.maxnbc = std::max(L.maxnbc, ch.nb);
+          }
         }
+        L.sc_cnt = hsc.size() - L.sc_off;
       }
-      dmalloc(&h->d_solve, sn.size() * sizeof(SolveNode<T>));
-      HS_HIP(hipMemcpy(h->d_solve, sn.data(), sn.size() * sizeof(SolveNode<T>), hipMemcpyHostToDevice));
-      dmalloc(&h->d_w1, (size_t)(woff + 1) * sizeof(T));
-      dmalloc(&h->d_w2, (size_t)(woff + 1) * sizeof(T));
-      dmalloc(&h->d_part, (size_t)(poff + 1) * sizeof(T));
-      dmalloc(&h->d_b, (size_t)n * sizeof(T));
-      h->part_elems = poff;
+      dmalloc(&h->d_nodes, hn.size() * sizeof(NodeDesc<T>), "front descriptors");
+      dmalloc(&h->d_sc, hsc.size() * sizeof(ScatterDesc<T>), "scatter descriptors");
+      dmalloc(&h->d_solve, sn.size() * sizeof(SolveNode<T>), "solve descriptors");
+      if (!hn.empty()) HS_HIP(hipMemcpy(h->d_nodes, hn.data(), hn.size() * sizeof(NodeDesc<T>), hipMemcpyHostToDevice));
+      if (!hsc.empty()) HS_HIP(hipMemcpy(h->d_sc, hsc.data(), hsc.size() * sizeof(ScatterDesc<T>), hipMemcpyHostToDevice));
+      if (!sn.empty()) HS_HIP(hipMemcpy(h->d_solve, sn.data(), sn.size() * sizeof(SolveNode<T>), hipMemcpyHostToDevice));
     }
+    dmalloc(&h->d_w1, (size_t)(woff + 1) * sizeof(T), "solve workspace");
+    dmalloc(&h->d_w2, (size_t)(woff + 1) * sizeof(T), "solve workspace");
+    dmalloc(&h->d_part, (size_t)(poff + 1) * sizeof(T), "solve partial sums");
+    dmalloc(&h->d_b, (size_t)n * sizeof(T), "right-hand side");
 
-    // ---- stats -----------------------------------------------------------------------------------------
     hs_stats& st = h->stats;
     st.n = n;
     st.nnodes = h->nreal;
     st.nlevels = nlev;
     for (int i = 0; i < h->nnodes; ++i) {
+      if (!N[i].mine) continue;
       st.max_ni = std::max<int64_t>(st.max_ni, N[i].ni);
       st.max_nb = std::max<int64_t>(st.max_nb, N[i].nb);
       st.bytes_solve += ((double)N[i].ni * N[i].ni + 2.0 * N[i].ni * N[i].nb) * sizeof(T);
     }
     st.bytes_solve += 3.0 * n * sizeof(T);
-    st.flops_factor = flops * (h->is_complex ? 4.0 : 1.0);
+    st.flops_factor = h->flops * (h->is_complex ? 4.0 : 1.0);
     st.bytes_factors = (double)(fac + inv) * sizeof(T);
     return h;
   } catch (...) {
@@ -629,22 +631,231 @@ static hs_handle* factor_impl(int64_t n, const int64_t* colptr, const int64_t* r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// numeric factorization
+// ------------------------------------------------------------------------------------------------
+static void check_handle(const hs_handle* h) {
+  if (!h) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: null factorization handle");
+}
+
 template <class T>
-static int factor_entry(int64_t n, const int64_t* colptr, const int64_t* rowval, const T* nzval, const hs_tree* tree,
-                        const hs_options* opts, hs_handle** out) {
+static void numeric_begin(hs_handle* h, const void* nzval, int on_device) {
+  if (!nzval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: nzval == NULL");
+  hipStream_t s = h->stream;
+  HS_HIP(hipMemcpyAsync(h->d_nz, nzval, h->nnz * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  HS_HIP(hipMemsetAsync(h->d_own, 0xff, h->n * sizeof(int), s));
+  h->prof = Profiler();
+  h->prof.on = h->opts.profile != 0;
+  HS_HIP(hipEventRecord(h->ev0, s));
+  h->numeric_open = true;
+  h->factored = false;
+}
+
+template <class T>
+static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
+  if (!h->numeric_open) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_numeric_levels before hs_numeric_begin");
+  const int nl = (int)h->levels.size();
+  lv_from = std::min(lv_from, nl - 1);
+  lv_to = std::max(lv_to, 0);
+  hipStream_t s = h->stream;
+  T* dfac = (T*)h->d_fac;
+  T* dsb = (T*)h->d_sb;
+  const NodeDesc<T>* dn_all = (const NodeDesc<T>*)h->d_nodes;
+  const ScatterDesc<T>* dsc_all = (const ScatterDesc<T>*)h->d_sc;
+  for (int lv = lv_from; lv >= lv_to; --lv) {
+    LevelH& L = h->levels[lv];
+    if (L.mine.empty()) continue;
+    const NodeDesc<T>* dn = dn_all + L.desc_off;
+    const int nb_ = (int)L.mine.size();
+    hipEvent_t ea = h->prof.begin(s);
+    // zero-fill this level's fronts: LF/UR are contiguous per level; SB of the owned fronts only
+    // (a ghost child's SB holds received data and must survive)
+    if (L.lf_end > L.lf_begin) HS_HIP(hipMemsetAsync(dfac + L.lf_begin, 0, (L.lf_end - L.lf_begin) * sizeof(T), s));
+    if (h->nranks == 1) {
+      if (L.sb_end > L.sb_begin) HS_HIP(hipMemsetAsync(dsb + L.sb_begin, 0, (L.sb_end - L.sb_begin) * sizeof(T), s));
+    } else {
+      for (int id : L.mine) {
+        const NodeH& x = h->nodes[id];
+        if (x.nb == 0) continue;
+        T* sb = x.ext_sb ? (T*)x.ext_sb : dsb + x.off_SB;
+        HS_HIP(hipMemsetAsync(sb, 0, (size_t)x.lds * x.nb * sizeof(T), s));
+      }
+    }
+    launch_init_fronts<T>(dn, nb_, L.maxni, s);
+    launch_mark<T>(dn, nb_, L.maxm, h->d_own, h->d_pos, s);
+    launch_gather<T>(dn, nb_, L.maxm, h->d_colptr, h->d_rowval, (const T*)h->d_nz, h->d_own, h->d_pos, s);
+    launch_scatter<T>(dn, dsc_all + L.sc_off, (int)L.sc_cnt, L.maxnbc, s);
+    h->prof.end(ea, HS_CAT_ASSEMBLE, s);
+    Sched<T> sch{dn, nb_, L.maxni, L.maxnb, L.maxm, s, &h->prof, L.h_ni.data(), L.h_nb.data()};
+    sch.factor_fronts();
+  }
+}
+
+static void numeric_end(hs_handle* h) {
+  if (!h->numeric_open) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_numeric_end before hs_numeric_begin");
+  hipStream_t s = h->stream;
+  HS_HIP(hipEventRecord(h->ev1, s));
+  HS_HIP(hipStreamSynchronize(s));
+  h->numeric_open = false;
+  float ms = 0.f;
+  HS_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->stats.t_total = ms * 1e-3;
+  Profiler& prof = h->prof;
+  prof.collect();
+  h->stats.t_gemm = prof.ms[HS_CAT_GEMM] * 1e-3;
+  h->stats.t_panel = prof.ms[HS_CAT_PANEL] * 1e-3;
+  h->stats.t_trsm = (prof.ms[HS_CAT_TRSM] + prof.ms[HS_CAT_LASWP]) * 1e-3;
+  h->stats.t_assemble = prof.ms[HS_CAT_ASSEMBLE] * 1e-3;
+  h->stats.gemm_flops = prof.flops[HS_CAT_GEMM];
+  h->stats.gemm_launches = prof.launches[HS_CAT_GEMM];
+  std::vector<int> info(h->nnodes);
+  HS_HIP(hipMemcpy(info.data(), h->d_info, h->nnodes * sizeof(int), hipMemcpyDeviceToHost));
+  for (int i = 0; i < h->nnodes; ++i)
+    if (h->nodes[i].mine && info[i] != 0)
+      HS_FAIL(HS_ERR_SINGULAR, i, "SingularException(%d): exactly zero pivot in the interior block of node %d (ni=%d, nb=%d)", info[i], i,
+              h->nodes[i].ni, h->nodes[i].nb);
+  h->factored = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ldiv!
+// ------------------------------------------------------------------------------------------------
+template <class T>
+static void solve_fwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s) {
+  const SolveNode<T>* sn = (const SolveNode<T>*)h->d_solve;
+  T* w1 = (T*)h->d_w1;
+  T* w2 = (T*)h->d_w2;
+  const int nl = (int)h->levels.size();
+  lv_from = std::min(lv_from, nl - 1);
+  lv_to = std::max(lv_to, 0);
+  for (int lv = lv_from; lv >= lv_to; --lv) {  // leaves -> root (-> pseudo-root)
+    const LevelH& L = h->levels[lv];
+    if (L.mine.empty() || L.maxni == 0) continue;
+    const SolveNode<T>* dn = sn + L.desc_off;
+    const int nb_ = (int)L.mine.size();
+    launch_fwd_gather<T>(dn, nb_, L.maxni, db, w1, s);
+    const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
+    for (int blk = 0; blk < nblk; ++blk) launch_fwd_step<T>(dn, nb_, blk, L.maxm, w1, w2, db, s);
+  }
+}
+template <class T>
+static void solve_bwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s) {
+  const SolveNode<T>* sn = (const SolveNode<T>*)h->d_solve;
+  T* w1 = (T*)h->d_w1;
+  T* w2 = (T*)h->d_w2;
+  T* part = (T*)h->d_part;
+  const int nl = (int)h->levels.size();
+  lv_from = std::max(lv_from, 0);
+  lv_to = std::min(lv_to, nl - 1);
+  for (int lv = lv_from; lv <= lv_to; ++lv) {  // root -> leaves
+    const LevelH& L = h->levels[lv];
+    if (L.mine.empty() || L.maxni == 0) continue;
+    const SolveNode<T>* dn = sn + L.desc_off;
+    const int nb_ = (int)L.mine.size();
+    launch_int_update<T>(dn, nb_, L.maxni, L.maxnb, db, part, w2, w1, s);
+    const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
+    for (int blk = nblk - 1; blk >= 0; --blk) launch_bwd_step<T>(dn, nb_, blk, w1, w2, s);
+    launch_bwd_scatter<T>(dn, nb_, L.maxni, db, w2, s);
+  }
+}
+
+static void check_solve_args(const hs_handle* h, bool cplx, int64_t ldc, int64_t ldb, int64_t n, int64_t nrhs) {
+  check_handle(h);
+  if (!h->factored) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: factorization is not complete");
+  if (h->is_complex != cplx) HS_FAIL(HS_ERR_ARGUMENT, 0, "MethodError: eltype of F and B differ");
+  if (n != h->n || ldc < n || ldb < n || nrhs < 0)
+    HS_FAIL(HS_ERR_DIMENSION, 0, "DimensionMismatch: B has %lld rows, F is %lld x %lld", (long long)n, (long long)h->n, (long long)h->n);
+}
+
+template <class T>
+static void ldiv_host(hs_handle* h, T* C, int64_t ldc, const T* B, int64_t ldb, int64_t n, int64_t nrhs) {
+  check_solve_args(h, sizeof(T) == 16, ldc, ldb, n, nrhs);
+  if (h->nranks > 1) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_ldiv_* on a distributed factorization: drive hs_solve_*_levels from the host layer");
+  hipStream_t s = h->stream;
+  double tsum = 0.0;
+  const int nl = (int)h->levels.size();
+  for (int64_t r = 0; r < nrhs; ++r) {
+    T* db = (T*)h->d_b;
+    HS_HIP(hipMemcpyAsync(db, B + r * ldb, n * sizeof(T), hipMemcpyHostToDevice, s));
+    HS_HIP(hipEventRecord(h->ev0, s));
+    solve_fwd<T>(h, db, nl - 1, 0, s);
+    solve_bwd<T>(h, db, 0, nl - 1, s);
+    HS_HIP(hipEventRecord(h->ev1, s));
+    HS_HIP(hipMemcpyAsync(C + r * ldc, db, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    HS_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HS_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    tsum += ms * 1e-3;
+  }
+  h->stats.t_solve = tsum;
+}
+
+template <class T>
+static void ldiv_dev(hs_handle* h, T* dC, int64_t ldc, const T* dB, int64_t ldb, int64_t n, int64_t nrhs, void* stream) {
+  check_solve_args(h, sizeof(T) == 16, ldc, ldb, n, nrhs);
+  if (h->nranks > 1) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_ldiv_dev_* on a distributed factorization: drive hs_solve_*_levels from the host layer");
+  hipStream_t s = (hipStream_t)stream;
+  const int nl = (int)h->levels.size();
+  for (int64_t r = 0; r < nrhs; ++r) {
+    T* c = dC + r * ldc;
+    if (c != dB + r * ldb) HS_HIP(hipMemcpyAsync(c, dB + r * ldb, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    solve_fwd<T>(h, c, nl - 1, 0, s);
+    solve_bwd<T>(h, c, 0, nl - 1, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int hs_analyze(int is_complex, int64_t n, const int64_t* colptr, const int64_t* rowval, const hs_tree* tree, const hs_options* opts,
+                          int64_t rank, int64_t nranks, hs_handle** out) {
   if (!out) {
     hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: out == NULL");
     return HS_ERR_ARGUMENT;
   }
   *out = nullptr;
+  HS_GUARD(*out = is_complex ? analyze_impl<cplx>(n, colptr, rowval, tree, opts, (int)rank, (int)nranks)
+                             : analyze_impl<double>(n, colptr, rowval, tree, opts, (int)rank, (int)nranks));
+}
+
+extern "C" int hs_numeric_begin(hs_handle* h, const void* nzval, int on_device) {
+  HS_GUARD(check_handle(h); if (h->is_complex) numeric_begin<cplx>(h, nzval, on_device); else numeric_begin<double>(h, nzval, on_device));
+}
+extern "C" int hs_numeric_levels(hs_handle* h, int64_t lv_from, int64_t lv_to) {
+  HS_GUARD(check_handle(h); if (h->is_complex) numeric_levels<cplx>(h, (int)lv_from, (int)lv_to);
+           else numeric_levels<double>(h, (int)lv_from, (int)lv_to));
+}
+extern "C" int hs_numeric_end(hs_handle* h) { HS_GUARD(check_handle(h); numeric_end(h)); }
+
+template <class T>
+static int factor_entry(int64_t n, const int64_t* colptr, const int64_t* rowval, const T* nzval, const hs_tree* tree, const hs_options* opts,
+                        hs_handle** out) {
+  if (!out) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: out == NULL");
+    return HS_ERR_ARGUMENT;
+  }
+  *out = nullptr;
+  hs_handle* h = nullptr;
   try {
-    *out = factor_impl<T>(n, colptr, rowval, nzval, tree, opts);
+    if (!nzval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: nzval == NULL");
+    h = analyze_impl<T>(n, colptr, rowval, tree, opts, 0, 1);
+    numeric_begin<T>(h, nzval, 0);
+    numeric_levels<T>(h, (int)h->levels.size() - 1, 0);
+    numeric_end(h);
+    if (!h->sb_kept) {  // one-shot path: the Schur scratch is not needed again
+      (void)hipFree(h->d_sb);
+      h->d_sb = nullptr;
+    }
+    *out = h;
     return HS_OK;
   } catch (const HsError& e) {
+    free_handle(h);
     return e.code;
   } catch (int code) {
+    free_handle(h);
     return code;
   } catch (const std::bad_alloc&) {
+    free_handle(h);
     hs_set_error(HS_ERR_NOMEM, 0, "host allocation failed");
     return HS_ERR_NOMEM;
   }
@@ -659,104 +870,96 @@ extern "C" int hs_factor_z(int64_t n, const int64_t* colptr, const int64_t* rowv
   return factor_entry<cplx>(n, colptr, rowval, reinterpret_cast<const cplx*>(nzval), tree, opts, out);
 }
 
-// ------------------------------------------------------------------------------------------------
-// ldiv!
-// ------------------------------------------------------------------------------------------------
-template <class T>
-static void solve_one(hs_handle* h, T* db, hipStream_t s) {
-  const SolveNode<T>* sn = (const SolveNode<T>*)h->d_solve;
-  T* w1 = (T*)h->d_w1;
-  T* w2 = (T*)h->d_w2;
-  T* part = (T*)h->d_part;
-  const int nl = (int)h->levels.size();
-  // forward: leaves -> root (-> pseudo-root)
-  for (int lv = nl - 1; lv >= 0; --lv) {
-    const LevelH& L = h->levels[lv];
-    if (L.nodes.empty() || L.maxni == 0) continue;
-    const SolveNode<T>* dn = sn + L.solve_off;
-    const int nb_ = (int)L.nodes.size();
-    launch_fwd_gather<T>(dn, nb_, L.maxni, db, w1, s);
-    const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
-    for (int blk = 0; blk < nblk; ++blk) launch_fwd_step<T>(dn, nb_, blk, L.maxm, w1, w2, db, s);
-  }
-  // backward: root -> leaves
-  for (int lv = 0; lv < nl; ++lv) {
-    const LevelH& L = h->levels[lv];
-    if (L.nodes.empty() || L.maxni == 0) continue;
-    const SolveNode<T>* dn = sn + L.solve_off;
-    const int nb_ = (int)L.nodes.size();
-    launch_int_update<T>(dn, nb_, L.maxni, L.maxnb, db, part, w2, w1, s);
-    const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
-    for (int blk = nblk - 1; blk >= 0; --blk) launch_bwd_step<T>(dn, nb_, blk, w1, w2, s);
-    launch_bwd_scatter<T>(dn, nb_, L.maxni, db, w2, s);
-  }
-}
-
-template <class T>
-static int ldiv_host(hs_handle* h, T* C, int64_t ldc, const T* B, int64_t ldb, int64_t n, int64_t nrhs) {
-  try {
-    if (!h) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: null factorization handle");
-    if (h->is_complex != (sizeof(T) == 16)) HS_FAIL(HS_ERR_ARGUMENT, 0, "MethodError: eltype of F and B differ");
-    if (n != h->n || ldc < n || ldb < n || nrhs < 0) HS_FAIL(HS_ERR_DIMENSION, 0, "DimensionMismatch: B has %lld rows, F is %lld x %lld", (long long)n, (long long)h->n, (long long)h->n);
-    hipStream_t s = h->stream;
-    hipEvent_t e0, e1;
-    HS_HIP(hipEventCreate(&e0));
-    HS_HIP(hipEventCreate(&e1));
-    double tsum = 0.0;
-    for (int64_t r = 0; r < nrhs; ++r) {
-      T* db = (T*)h->d_b;
-      HS_HIP(hipMemcpyAsync(db, B + r * ldb, n * sizeof(T), hipMemcpyHostToDevice, s));
-      HS_HIP(hipEventRecord(e0, s));
-      solve_one<T>(h, db, s);
-      HS_HIP(hipEventRecord(e1, s));
-      HS_HIP(hipMemcpyAsync(C + r * ldc, db, n * sizeof(T), hipMemcpyDeviceToHost, s));
-      HS_HIP(hipStreamSynchronize(s));
-      float ms = 0.f;
-      HS_HIP(hipEventElapsedTime(&ms, e0, e1));
-      tsum += ms * 1e-3;
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    h->stats.t_solve = tsum;
-    return HS_OK;
-  } catch (const HsError& e) {
-    return e.code;
-  } catch (int code) {
-    return code;
-  }
-}
-
-template <class T>
-static int ldiv_dev(hs_handle* h, T* dC, int64_t ldc, const T* dB, int64_t ldb, int64_t n, int64_t nrhs, void* stream) {
-  try {
-    if (!h) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: null factorization handle");
-    if (h->is_complex != (sizeof(T) == 16)) HS_FAIL(HS_ERR_ARGUMENT, 0, "MethodError: eltype of F and B differ");
-    if (n != h->n || ldc < n || ldb < n || nrhs < 0) HS_FAIL(HS_ERR_DIMENSION, 0, "DimensionMismatch");
-    hipStream_t s = (hipStream_t)stream;
-    for (int64_t r = 0; r < nrhs; ++r) {
-      T* c = dC + r * ldc;
-      if (c != dB + r * ldb) HS_HIP(hipMemcpyAsync(c, dB + r * ldb, n * sizeof(T), hipMemcpyDeviceToDevice, s));
-      solve_one<T>(h, c, s);
-    }
-    return HS_OK;
-  } catch (const HsError& e) {
-    return e.code;
-  } catch (int code) {
-    return code;
-  }
-}
-
 extern "C" int hs_ldiv_d(hs_handle* F, double* C, int64_t ldc, const double* B, int64_t ldb, int64_t n, int64_t nrhs) {
-  return ldiv_host<double>(F, C, ldc, B, ldb, n, nrhs);
+  HS_GUARD(ldiv_host<double>(F, C, ldc, B, ldb, n, nrhs));
 }
 extern "C" int hs_ldiv_z(hs_handle* F, double* C, int64_t ldc, const double* B, int64_t ldb, int64_t n, int64_t nrhs) {
-  return ldiv_host<cplx>(F, (cplx*)C, ldc, (const cplx*)B, ldb, n, nrhs);
+  HS_GUARD(ldiv_host<cplx>(F, (cplx*)C, ldc, (const cplx*)B, ldb, n, nrhs));
 }
 extern "C" int hs_ldiv_dev_d(hs_handle* F, double* dC, int64_t ldc, const double* dB, int64_t ldb, int64_t n, int64_t nrhs, void* stream) {
-  return ldiv_dev<double>(F, dC, ldc, dB, ldb, n, nrhs, stream);
+  HS_GUARD(ldiv_dev<double>(F, dC, ldc, dB, ldb, n, nrhs, stream));
 }
 extern "C" int hs_ldiv_dev_z(hs_handle* F, double* dC, int64_t ldc, const double* dB, int64_t ldb, int64_t n, int64_t nrhs, void* stream) {
-  return ldiv_dev<cplx>(F, (cplx*)dC, ldc, (const cplx*)dB, ldb, n, nrhs, stream);
+  HS_GUARD(ldiv_dev<cplx>(F, (cplx*)dC, ldc, (const cplx*)dB, ldb, n, nrhs, stream));
+}
+
+extern "C" int hs_solve_fwd_levels(hs_handle* h, void* d_b, int64_t lv_from, int64_t lv_to, void* stream) {
+  HS_GUARD(check_handle(h); if (h->is_complex) solve_fwd<cplx>(h, (cplx*)d_b, (int)lv_from, (int)lv_to, (hipStream_t)stream);
+           else solve_fwd<double>(h, (double*)d_b, (int)lv_from, (int)lv_to, (hipStream_t)stream));
+}
+extern "C" int hs_solve_bwd_levels(hs_handle* h, void* d_b, int64_t lv_from, int64_t lv_to, void* stream) {
+  HS_GUARD(check_handle(h); if (h->is_complex) solve_bwd<cplx>(h, (cplx*)d_b, (int)lv_from, (int)lv_to, (hipStream_t)stream);
+           else solve_bwd<double>(h, (double*)d_b, (int)lv_from, (int)lv_to, (hipStream_t)stream));
+}
+
+// ---- multi-rank plumbing: who owns what, which Schur complements / boundary vectors cross ranks ----------------
+extern "C" int64_t hs_nlevels(const hs_handle* h) { return h ? (int64_t)h->levels.size() - 1 : 0; }
+extern "C" int64_t hs_cut_level(const hs_handle* h) { return h ? h->cut_level : 0; }
+extern "C" int64_t hs_num_exchanges(const hs_handle* h) { return h ? (int64_t)h->exchanges.size() : 0; }
+extern "C" int hs_exchange_info(const hs_handle* h, int64_t k, int64_t* out6) {
+  HS_GUARD(check_handle(h);
+           if (k < 0 || k >= (int64_t)h->exchanges.size() || !out6) HS_FAIL(HS_ERR_ARGUMENT, k, "BoundsError: exchange %lld", (long long)k);
+           const Exchange& e = h->exchanges[k]; out6[0] = e.node; out6[1] = e.level; out6[2] = e.src; out6[3] = e.dst; out6[4] = e.nb;
+           out6[5] = e.nelems);
+}
+extern "C" int64_t hs_node_owner(const hs_handle* h, int64_t node) {
+  if (!h || node < 0 || node >= h->nnodes) return -1;
+  return h->nodes[node].owner;
+}
+
+template <class T>
+static void set_schur_buffer(hs_handle* h, int node, void* dptr) {
+  NodeH& x = h->nodes[node];
+  if (!(x.mine || x.ghost)) HS_FAIL(HS_ERR_ARGUMENT, node, "ArgumentError: node %d is neither owned nor received by rank %d", node, h->rank);
+  x.ext_sb = dptr;
+  T* p = (T*)dptr;
+  if (x.mine) {  // the front's own descriptor
+    NodeDesc<T>* d = (NodeDesc<T>*)h->d_nodes + h->levels[x.level].desc_off + x.batch_pos;
+    HS_HIP(hipMemcpy(&d->SB, &p, sizeof p, hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(&d->mp[2], &p, sizeof p, hipMemcpyHostToDevice));
+  }
+  if (x.parent >= 0 && h->nodes[x.parent].mine) {  // the parent's scatter descriptor (stored left child first)
+    const LevelH& L = h->levels[h->nodes[x.parent].level];
+    size_t k = L.sc_off;
+    for (int id : L.mine) {
+      const NodeH& y = h->nodes[id];
+      for (int side = 0; side < 2; ++side) {
+        int c = side == 0 ? y.left : y.right;
+        if (y.leaf || c < 0 || h->nodes[c].nb == 0) continue;
+        if (c == node) {
+          ScatterDesc<T>* sc = (ScatterDesc<T>*)h->d_sc + k;
+          const T* cp = p;
+          HS_HIP(hipMemcpy(&sc->S, &cp, sizeof cp, hipMemcpyHostToDevice));
+        }
+        ++k;
+      }
+    }
+  }
+}
+extern "C" int hs_set_schur_buffer(hs_handle* h, int64_t node, void* dptr) {
+  HS_GUARD(check_handle(h); if (node < 0 || node >= h->nnodes || !dptr) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+           if (h->is_complex) set_schur_buffer<cplx>(h, (int)node, dptr); else set_schur_buffer<double>(h, (int)node, dptr));
+}
+// buf[j] = b[bnd_j(node)] and back: the boundary segment of a front as a contiguous vector
+extern "C" int hs_pack_bnd(const hs_handle* h, int64_t node, const void* d_b, void* d_buf, void* stream) {
+  HS_GUARD(check_handle(h); if (node < 0 || node >= h->nnodes) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+           const NodeH& x = h->nodes[node];
+           launch_pack_idx(h->d_int + x.off_fidx + x.ni, x.nb, d_b, d_buf, h->is_complex ? 16 : 8, (hipStream_t)stream));
+}
+extern "C" int hs_unpack_bnd(const hs_handle* h, int64_t node, void* d_b, const void* d_buf, void* stream) {
+  HS_GUARD(check_handle(h); if (node < 0 || node >= h->nnodes) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+           const NodeH& x = h->nodes[node];
+           launch_unpack_idx(h->d_int + x.off_fidx + x.ni, x.nb, d_b, d_buf, h->is_complex ? 16 : 8, (hipStream_t)stream));
+}
+// d_out (zero-filled by the caller) receives the solution entries this rank owns: out[int(node)] = b[int(node)]
+extern "C" int hs_extract_owned(const hs_handle* h, const void* d_b, void* d_out, void* stream) {
+  HS_GUARD(check_handle(h); const int esz = h->is_complex ? 16 : 8; for (int i = 0; i < h->nnodes; ++i) {
+    const NodeH& x = h->nodes[i];
+    if (!x.mine || x.ni == 0) continue;
+    char* tmp = (char*)h->d_w1 + (size_t)x.woff * esz;
+    launch_pack_idx(h->d_int + x.off_fidx, x.ni, d_b, tmp, esz, (hipStream_t)stream);
+    launch_unpack_idx(h->d_int + x.off_fidx, x.ni, d_out, tmp, esz, (hipStream_t)stream);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -792,6 +995,7 @@ extern "C" int hs_node_info(const hs_handle* F, int64_t node, int64_t* ni, int64
 
 template <class T>
 static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) {
+  if (!x.mine) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: node is owned by rank %d", x.owner);
   const T* base;
   int rows, cols, ld;
   switch (which) {
@@ -800,7 +1004,7 @@ static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) 
     case HS_BLK_UIB: base = (const T*)F->d_fac + x.off_UR; rows = x.ni; cols = x.nb; ld = x.ldu; break;
     case HS_BLK_S:
       if (!F->sb_kept || !F->d_sb) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: Schur complements were not kept (opts.keep_schur)");
-      base = (const T*)F->d_sb + x.off_SB; rows = x.nb; cols = x.nb; ld = x.lds; break;
+      base = x.ext_sb ? (const T*)x.ext_sb : (const T*)F->d_sb + x.off_SB; rows = x.nb; cols = x.nb; ld = x.lds; break;
     default: HS_FAIL(HS_ERR_ARGUMENT, which, "ArgumentError: unknown block id %d", which);
   }
   if (rows == 0 || cols == 0) return;
@@ -808,33 +1012,16 @@ static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) 
 }
 
 extern "C" int hs_node_export(const hs_handle* F, int64_t node, int which, double* out) {
-  try {
-    if (!F || node < 0 || node >= F->nnodes || !out) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
-    if (F->is_complex)
-      export_block<cplx>(F, F->nodes[node], which, (cplx*)out);
-    else
-      export_block<double>(F, F->nodes[node], which, out);
-    return HS_OK;
-  } catch (const HsError& e) {
-    return e.code;
-  } catch (int code) {
-    return code;
-  }
+  HS_GUARD(check_handle(F); if (node < 0 || node >= F->nnodes || !out) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+           if (F->is_complex) export_block<cplx>(F, F->nodes[node], which, (cplx*)out); else export_block<double>(F, F->nodes[node], which, out));
 }
 
 extern "C" int hs_node_export_piv(const hs_handle* F, int64_t node, int64_t* out) {
-  try {
-    if (!F || node < 0 || node >= F->nnodes || !out) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
-    const NodeH& x = F->nodes[node];
-    std::vector<int> tmp(x.ni);
-    if (x.ni) HS_HIP(hipMemcpy(tmp.data(), F->d_int + x.off_rperm, x.ni * sizeof(int), hipMemcpyDeviceToHost));
-    for (int i = 0; i < x.ni; ++i) out[i] = tmp[i];
-    return HS_OK;
-  } catch (const HsError& e) {
-    return e.code;
-  } catch (int code) {
-    return code;
-  }
+  HS_GUARD(check_handle(F); if (node < 0 || node >= F->nnodes || !out) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+           const NodeH& x = F->nodes[node]; if (!x.mine) HS_FAIL(HS_ERR_ARGUMENT, node, "ArgumentError: node is owned by rank %d", x.owner);
+           std::vector<int> tmp(x.ni);
+           if (x.ni) HS_HIP(hipMemcpy(tmp.data(), F->d_int + x.off_rperm, x.ni * sizeof(int), hipMemcpyDeviceToHost));
+           for (int i = 0; i < x.ni; ++i) out[i] = tmp[i]);
 }
 
 extern "C" int hs_device_info(char* arch_name, int64_t len, int64_t* cu_count, int64_t* hbm_bytes) {

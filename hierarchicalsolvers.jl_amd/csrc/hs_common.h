@@ -71,6 +71,7 @@ struct NodeDesc {
   T* invL;       // ceil(ni/32) blocks of 32x32 (column-major, ld 32): inverse of the unit-lower diagonal block
   T* invU;       // same for the upper diagonal block
   int* ipiv;     // ni entries: LAPACK-style swap targets (0-based row inside the front)
+  int* rperm;    // ni entries: accumulated row permutation, (P x)[i] = x[rperm[i]] (used by ldiv!)
   int* cand0;    // tournament candidate lists (ping-pong)
   int* cand1;
   int* pivlist;  // HS_PB selected rows of the current panel
@@ -141,6 +142,8 @@ template <class T>
 void launch_trsm_blk(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int c0, int c1, int maxcols, hipStream_t s);
 
 template <class T>
+void launch_init_fronts(const NodeDesc<T>* dnodes, int nbatch, int maxni, hipStream_t s);  // rperm = 0:ni-1, info = 0
+template <class T>
 void launch_mark(const NodeDesc<T>* dnodes, int nbatch, int maxm, int* own, int* pos, hipStream_t s);
 template <class T>
 void launch_gather(const NodeDesc<T>* dnodes, int nbatch, int maxm, const int64_t* colptr, const int32_t* rowval,
@@ -178,6 +181,9 @@ template <class T>
 void launch_bwd_step(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s);
 template <class T>
 void launch_bwd_scatter(const SolveNode<T>* dn, int nbatch, int maxni, T* b, const T* x, hipStream_t s);
+
+void launch_pack_idx(const int* idx, int cnt, const void* b, void* buf, int esz, hipStream_t s);    // buf[i] = b[idx[i]]
+void launch_unpack_idx(const int* idx, int cnt, void* b, const void* buf, int esz, hipStream_t s);  // b[idx[i]] = buf[i]
 
 void hs_set_error(int code, long long info, const char* fmt, ...);
 

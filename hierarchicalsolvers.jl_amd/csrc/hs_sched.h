@@ -8,16 +8,60 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include "../../include/hs_solver.h"
 #include "hs_common.h"
 
 // ------------------------------------------------------------------------------------------------
+// Optional per-launch timing (opts.profile): a HIP event pair around every launch, on the stream the
+// kernels run on, summed per category after the factorization.  Off by default (events add gaps).
+enum { HS_CAT_GEMM = 0, HS_CAT_PANEL = 1, HS_CAT_LASWP = 2, HS_CAT_TRSM = 3, HS_CAT_ASSEMBLE = 4, HS_NCAT = 5 };
+struct Profiler {
+  bool on = false;
+  struct Rec {
+    hipEvent_t e0, e1;
+    int cat;
+  };
+  std::vector<Rec> recs;
+  double flops[HS_NCAT] = {0, 0, 0, 0, 0};
+  double ms[HS_NCAT] = {0, 0, 0, 0, 0};
+  long long launches[HS_NCAT] = {0, 0, 0, 0, 0};
+  hipEvent_t begin(hipStream_t s) {
+    hipEvent_t e = nullptr;
+    if (on) {
+      (void)hipEventCreate(&e);
+      (void)hipEventRecord(e, s);
+    }
+    return e;
+  }
+  void end(hipEvent_t e0, int cat, hipStream_t s, double fl = 0.0) {
+    launches[cat]++;
+    flops[cat] += fl;
+    if (!on) return;
+    hipEvent_t e1;
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e1, s);
+    recs.push_back({e0, e1, cat});
+  }
+  void collect() {  // call after the stream has been synchronised
+    for (auto& r : recs) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) ms[r.cat] += t;
+      (void)hipEventDestroy(r.e0);
+      (void)hipEventDestroy(r.e1);
+    }
+    recs.clear();
+  }
+};
+
 template <class T>
 struct Sched {
   const NodeDesc<T>* dn;
   int nbatch, maxni, maxnb, maxm;
   hipStream_t s;
-  hs_stats* st;
+  Profiler* pf;
+  const int* h_ni;  // per-front sizes on the host (exact flop accounting); may be null
+  const int* h_nb;
 
   // HS_DEBUG_SYNC=1: synchronise after every launch and report the first failing one (diagnostics only)
   void dbg(const char* what, int a = 0, int b = 0, int c = 0, int d = 0) {
@@ -39,14 +83,26 @@ struct Sched {
     GemmOp op{cmat, bmat, r0, r1, c0, c1, k0, k1};
     int M = std::min(r1, rows_of(cmat)) - r0, N = std::min(c1, cols_of(cmat)) - c0, K = std::min(k1, maxni) - k0;
     if (M <= 0 || N <= 0 || K <= 0) return;
+    double fl = 0.0;
+    if (h_ni) {
+      for (int i = 0; i < nbatch; ++i) {
+        int ni = h_ni[i], nb = h_nb[i], m = ni + nb;
+        int rows = cmat == HS_MAT_LF ? m : (cmat == HS_MAT_UR ? ni : nb), cols = cmat == HS_MAT_LF ? ni : nb;
+        double Mi = std::min(r1, rows) - r0, Ni = std::min(c1, cols) - c0, Ki = std::min(k1, ni) - k0;
+        if (Mi > 0 && Ni > 0 && Ki > 0) fl += 2.0 * Mi * Ni * Ki;
+      }
+      if (sizeof(T) == 16) fl *= 4.0;
+    }
+    hipEvent_t e0 = pf->begin(s);
     launch_gemm_op<T>(dn, nbatch, M, N, op, s);
-    st->gemm_launches++;
+    pf->end(e0, HS_CAT_GEMM, s, fl);
     dbg("gemm", cmat, r0, c0, k0);
   }
   void panel(int pb) {
     int c0 = pb * HS_PB;
     if (c0 >= maxni) return;
     int cnt = maxni - c0, nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
+    hipEvent_t e0 = pf->begin(s);
     for (int round = 0;; ++round) {
       launch_tournament_round<T>(dn, nbatch, pb, round, nch, s);
       dbg("tournament", pb, round, nch);
@@ -58,11 +114,14 @@ struct Sched {
     dbg("panel_pivot", pb);
     launch_panel_l21<T>(dn, nbatch, pb, maxm - c0, s);
     dbg("panel_l21", pb);
+    pf->end(e0, HS_CAT_PANEL, s);
   }
   void laswp(int mat, int c0, int c1, int k0, int k1) {
     int nc = std::min(c1, cols_of(mat)) - c0;
     if (nc <= 0 || k0 >= maxni) return;
+    hipEvent_t e0 = pf->begin(s);
     launch_laswp<T>(dn, nbatch, mat, c0, c1, k0, k1, nc, s);
+    pf->end(e0, HS_CAT_LASWP, s);
     dbg("laswp", mat, c0, k0, k1);
   }
   // X[r0:r1, c0:c1) <- L[r0:r1, r0:r1]^-1 X
@@ -71,7 +130,9 @@ struct Sched {
     int nc = std::min(c1, cols_of(mat)) - c0;
     if (nc <= 0) return;
     if (r1 - r0 == HS_PB) {
+      hipEvent_t e0 = pf->begin(s);
       launch_trsm_blk<T>(dn, nbatch, mat, r0, c0, c1, nc, s);
+      pf->end(e0, HS_CAT_TRSM, s);
       dbg("trsm_blk", mat, r0, c0, c1);
       return;
     }

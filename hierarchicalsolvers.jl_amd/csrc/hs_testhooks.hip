@@ -82,7 +82,7 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
   const int nblk = ((int)ni + HS_PB - 1) / HS_PB;
   const size_t eLF = (size_t)ldl * ni + 32, eUR = (size_t)ldu * nb + 32, eSB = (size_t)lds * nb + 32, eInv = (size_t)2 * nblk * 1024 + 32;
   const int ncand = (((int)ni + HS_CHUNK - 1) / HS_CHUNK + 1) * HS_PB;
-  const size_t eInt = (size_t)ni + 2 * ncand + HS_PB + 1;
+  const size_t eInt = (size_t)2 * ni + 2 * ncand + HS_PB + 1;
   T* dbuf = nullptr;
   int* dint = nullptr;
   NodeDesc<T>* dn = nullptr;
@@ -102,7 +102,8 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
     d.invL = d.SB + eSB;
     d.invU = d.invL + (size_t)nblk * 1024;
     d.ipiv = dint + eInt * k;
-    d.cand0 = d.ipiv + ni;
+    d.rperm = d.ipiv + ni;
+    d.cand0 = d.rperm + ni;
     d.cand1 = d.cand0 + ncand;
     d.pivlist = d.cand1 + ncand;
     d.info = d.pivlist + HS_PB;
@@ -116,13 +117,13 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
     if (nb > 0) CK(hipMemcpy2D(d.SB, sizeof(T) * lds, Fk + (size_t)m * ni + ni, sizeof(T) * m, sizeof(T) * nb, nb, hipMemcpyHostToDevice));
   }
   CK(hipMemcpy(dn, hn.data(), sizeof(NodeDesc<T>) * count, hipMemcpyHostToDevice));
-  hs_stats st;
-  memset(&st, 0, sizeof st);
+  Profiler prof;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   CK(hipEventRecord(e0, 0));
-  Sched<T> sch{dn, (int)count, (int)ni, (int)nb, m, 0, &st};
+  launch_init_fronts<T>(dn, (int)count, (int)ni, 0);
+  Sched<T> sch{dn, (int)count, (int)ni, (int)nb, m, 0, &prof, nullptr, nullptr};
   sch.factor_fronts();
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
@@ -136,16 +137,9 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
     if (ni > 0 && outLF) CK(hipMemcpy2D(outLF + (size_t)m * ni * k, sizeof(T) * m, d.LF, sizeof(T) * ldl, sizeof(T) * m, ni, hipMemcpyDeviceToHost));
     if (ni > 0 && nb > 0 && outUR) CK(hipMemcpy2D(outUR + (size_t)ni * nb * k, sizeof(T) * ni, d.UR, sizeof(T) * ldu, sizeof(T) * ni, nb, hipMemcpyDeviceToHost));
     if (nb > 0 && outSB) CK(hipMemcpy2D(outSB + (size_t)nb * nb * k, sizeof(T) * nb, d.SB, sizeof(T) * lds, sizeof(T) * nb, nb, hipMemcpyDeviceToHost));
-    if (ni > 0) CK(hipMemcpy(ip.data(), d.ipiv, sizeof(int) * ni, hipMemcpyDeviceToHost));
-    if (out_rperm) {
-      int64_t* rp = out_rperm + ni * k;
-      for (int64_t i = 0; i < ni; ++i) rp[i] = i;
-      for (int64_t i = 0; i < ni; ++i) {
-        int p = ip[i];
-        if (p < 0 || p >= ni) p = (int)i;
-        int64_t t = rp[i]; rp[i] = rp[p]; rp[p] = t;
-      }
-    }
+    if (ni > 0) CK(hipMemcpy(ip.data(), d.rperm, sizeof(int) * ni, hipMemcpyDeviceToHost));
+    if (out_rperm)
+      for (int64_t i = 0; i < ni; ++i) out_rperm[ni * k + i] = ip[i];
     int inf = 0;
     CK(hipMemcpy(&inf, d.info, sizeof(int), hipMemcpyDeviceToHost));
     if (info) info[k] = inf;

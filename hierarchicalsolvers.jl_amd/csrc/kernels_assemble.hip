@@ -37,6 +37,14 @@ __device__ inline int side_of(const NodeDesc<T>& nd, int p) {
 }
 
 template <class T>
+__global__ __launch_bounds__(256) void init_fronts_kernel(const NodeDesc<T>* __restrict__ nodes) {
+  const NodeDesc<T> nd = nodes[blockIdx.y];
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *nd.info = 0;
+  if (i < nd.ni) nd.rperm[i] = i;
+}
+
+template <class T>
 __global__ __launch_bounds__(256) void mark_kernel(const NodeDesc<T>* __restrict__ nodes, int* __restrict__ own, int* __restrict__ pos) {
   const NodeDesc<T> nd = nodes[blockIdx.y];
   int p = blockIdx.x * 256 + threadIdx.x;
@@ -87,6 +95,11 @@ __global__ __launch_bounds__(256) void scatter_kernel(const NodeDesc<T>* __restr
 }
 
 template <class T>
+void launch_init_fronts(const NodeDesc<T>* dnodes, int nbatch, int maxni, hipStream_t s) {
+  if (nbatch <= 0) return;
+  hipLaunchKernelGGL(init_fronts_kernel<T>, dim3(maxni > 0 ? (maxni + 255) / 256 : 1, nbatch), dim3(256), 0, s, dnodes);
+}
+template <class T>
 void launch_mark(const NodeDesc<T>* dnodes, int nbatch, int maxm, int* own, int* pos, hipStream_t s) {
   if (nbatch <= 0 || maxm <= 0) return;
   hipLaunchKernelGGL(mark_kernel<T>, dim3((maxm + 255) / 256, nbatch), dim3(256), 0, s, dnodes, own, pos);
@@ -105,6 +118,7 @@ void launch_scatter(const NodeDesc<T>* dnodes, const ScatterDesc<T>* dsc, int ns
 }
 
 #define INST(T)                                                                                                          \
+  template void launch_init_fronts<T>(const NodeDesc<T>*, int, int, hipStream_t);                                        \
   template void launch_mark<T>(const NodeDesc<T>*, int, int, int*, int*, hipStream_t);                                   \
   template void launch_gather<T>(const NodeDesc<T>*, int, int, const int64_t*, const int32_t*, const T*, const int*,    \
                                  const int*, hipStream_t);                                                               \

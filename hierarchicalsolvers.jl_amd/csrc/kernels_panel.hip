@@ -191,6 +191,16 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
         col[p] = tmp;
       }
     }
+  } else if (t == 64) {
+    // the accumulated row permutation is one more "column" that takes the same swaps
+    for (int k = 0; k < w; ++k) {
+      int p = s_piv[k];
+      if (p != c0 + k) {
+        int tmp = nd.rperm[c0 + k];
+        nd.rperm[c0 + k] = nd.rperm[p];
+        nd.rperm[p] = tmp;
+      }
+    }
   }
   __syncthreads();
   // load the top w x w block (identity-padded to 32)

@@ -132,6 +132,30 @@ __global__ __launch_bounds__(256) void bwd_scatter_kernel(const SolveNode<T>* __
   b[nd.fidx[i]] = x[nd.woff + i];
 }
 
+// ---- multi-rank helpers: boundary segments cross ranks as contiguous vectors ------------------------
+__global__ __launch_bounds__(256) void pack_idx_kernel(const int* __restrict__ idx, int cnt, const char* __restrict__ b, char* __restrict__ buf, int esz) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cnt) return;
+  const double* s = reinterpret_cast<const double*>(b + (size_t)idx[i] * esz);
+  double* d = reinterpret_cast<double*>(buf + (size_t)i * esz);
+  for (int k = 0; k < esz / 8; ++k) d[k] = s[k];
+}
+__global__ __launch_bounds__(256) void unpack_idx_kernel(const int* __restrict__ idx, int cnt, char* __restrict__ b, const char* __restrict__ buf, int esz) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cnt) return;
+  double* d = reinterpret_cast<double*>(b + (size_t)idx[i] * esz);
+  const double* s = reinterpret_cast<const double*>(buf + (size_t)i * esz);
+  for (int k = 0; k < esz / 8; ++k) d[k] = s[k];
+}
+void launch_pack_idx(const int* idx, int cnt, const void* b, void* buf, int esz, hipStream_t s) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(pack_idx_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, idx, cnt, (const char*)b, (char*)buf, esz);
+}
+void launch_unpack_idx(const int* idx, int cnt, void* b, const void* buf, int esz, hipStream_t s) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(unpack_idx_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, idx, cnt, (char*)b, (const char*)buf, esz);
+}
+
 // ---- launchers ---------------------------------------------------------------------------------
 template <class T>
 void launch_fwd_gather(const SolveNode<T>* dn, int nbatch, int maxni, const T* b, T* w, hipStream_t s) {

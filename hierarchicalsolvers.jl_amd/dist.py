@@ -1,0 +1,278 @@
+"""Staged (analyze / numeric / solve) driver with device-resident inputs, single- or multi-rank.
+
+One process per GPU.  The elimination tree is cut at level ``p+1`` (``nranks = 2^p``): the subtrees
+below go one per rank -- the reference factors them one after the other although they are independent
+(``src/factorization.jl:20-21``) -- and every front above the cut is eliminated by the first rank of
+its group.  Sibling Schur complements are *concatenated* into the parent front, never summed
+(``src/factorization.jl:118-121``), so a join needs no reduction: the right child's owner sends its
+Schur complement (``nb x nb``) to the parent's owner, point to point.  ``ldiv!`` mirrors it with
+``nb``-vectors: up in the forward sweep, down in the backward sweep, then one all-reduce of the
+disjoint solution pieces.
+
+The schedule below is written against a small *backend* interface so that the same code runs
+
+* on GPUs: :class:`HipBackend` (C ABI of ``libhs_solver.so``; ``torch.distributed`` backend ``nccl`` =
+  RCCL over xGMI moves the buffers, which are torch tensors registered with the library), and
+* in the CPU tests: an oracle-backed backend over ``gloo`` (tests/test_dist_cpu.py), which checks the
+  partition / exchange logic without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from .nesteddissection import flatten_tree
+from .solver import SolverOptions, chkopts
+
+__all__ = ["Plan", "HipBackend", "run_numeric", "run_solve", "StagedSolver"]
+
+
+class Plan:
+    """What the host layer needs to know about the partition: levels, cut and the cross-rank edges."""
+
+    def __init__(self, nlevels, cut_level, exchanges, nranks):
+        self.nlevels = int(nlevels)
+        self.cut_level = int(cut_level)
+        self.exchanges = list(exchanges)  # dicts: node, level (of the child), src, dst, nb, nelems
+        self.nranks = int(nranks)
+
+    def at_child_level(self, lv):
+        return [e for e in self.exchanges if e["level"] == lv]
+
+
+class _NullComm:
+    """nranks == 1: nothing crosses ranks."""
+
+    def send(self, t, dst):
+        raise RuntimeError("no peers")
+
+    def recv(self, t, src):
+        raise RuntimeError("no peers")
+
+    def all_reduce(self, t):
+        return t
+
+    def barrier(self):
+        pass
+
+
+class TorchComm:
+    """torch.distributed point-to-point + all-reduce (backend nccl = RCCL on ROCm; gloo on CPU)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+
+        self.dist = dist
+
+    def send(self, t, dst):
+        self.dist.send(t, dst=dst)
+
+    def recv(self, t, src):
+        self.dist.recv(t, src=src)
+
+    def all_reduce(self, t):
+        self.dist.all_reduce(t)
+        return t
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def run_numeric(backend, plan, rank, comm):
+    """Numeric factorization: rank-local subtrees, then the fronts above the cut level by level,
+    receiving the remote child's Schur complement before each join."""
+    backend.numeric_begin()
+    L, cut = plan.nlevels, plan.cut_level
+    backend.numeric_levels(L, cut)
+    for lv in range(cut - 1, 0, -1):
+        for e in plan.at_child_level(lv + 1):
+            if e["src"] == rank:
+                backend.sync()
+                comm.send(backend.schur_tensor(e["node"]), e["dst"])
+            elif e["dst"] == rank:
+                comm.recv(backend.schur_tensor(e["node"]), e["src"])
+                backend.comm_sync()
+        backend.numeric_levels(lv, lv)
+    backend.numeric_levels(0, 0)  # pseudo-root (root with a boundary), owned by rank 0
+    backend.numeric_end()
+
+
+def run_solve(backend, plan, rank, comm, b):
+    """``ldiv!`` in place on the (replicated) device vector ``b``; on return every rank holds the solution."""
+    L, cut = plan.nlevels, plan.cut_level
+    backend.fwd(b, L, cut)
+    for lv in range(cut - 1, 0, -1):
+        for e in plan.at_child_level(lv + 1):
+            if e["src"] == rank:
+                buf = backend.pack_bnd(e["node"], b)
+                backend.sync()
+                comm.send(buf, e["dst"])
+            elif e["dst"] == rank:
+                buf = backend.bnd_buffer(e["node"])
+                comm.recv(buf, e["src"])
+                backend.comm_sync()
+                backend.unpack_bnd(e["node"], b, buf)
+        backend.fwd(b, lv, lv)
+    backend.fwd(b, 0, 0)
+    backend.bwd(b, 0, 1)
+    for lv in range(1, cut):
+        for e in plan.at_child_level(lv + 1):
+            if e["dst"] == rank:  # parent's owner hands the boundary values back down
+                buf = backend.pack_bnd(e["node"], b)
+                backend.sync()
+                comm.send(buf, e["src"])
+            elif e["src"] == rank:
+                buf = backend.bnd_buffer(e["node"])
+                comm.recv(buf, e["dst"])
+                backend.comm_sync()
+                backend.unpack_bnd(e["node"], b, buf)
+        backend.bwd(b, lv + 1, lv + 1)
+    backend.bwd(b, cut + 1, L)
+    if plan.nranks > 1:
+        out = backend.extract_owned(b)
+        backend.sync()
+        comm.all_reduce(out)
+        backend.comm_sync()
+        backend.assign(b, out)
+    return b
+
+
+class HipBackend:
+    """The C ABI behind the schedule.  Device buffers that cross ranks are torch tensors."""
+
+    def __init__(self, A, nd, nd_loc, opts=None, rank=0, nranks=1, device=None, **kw):
+        import torch
+
+        self.torch = torch
+        opts = (opts or SolverOptions()).copy(**kw)
+        chkopts(opts)
+        A = sp.csc_matrix(A)
+        A.sort_indices()
+        self.n = A.shape[0]
+        self.is_c = bool(np.iscomplexobj(A.data))
+        self.np_dtype = np.complex128 if self.is_c else np.float64
+        self.t_dtype = torch.complex128 if self.is_c else torch.float64
+        self.device = torch.device(device if device is not None else "cuda:0")
+        torch.cuda.set_device(self.device)
+        self.rank, self.nranks = int(rank), int(nranks)
+        colptr = np.ascontiguousarray(A.indptr, dtype=np.int64) + 1
+        rowval = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
+        flat = flatten_tree(nd, nd_loc)
+        t = _lib.hs_tree()
+        t.nnodes = flat["nnodes"]
+        for k in ("left", "right", "int_ptr", "int_idx", "bnd_ptr", "bnd_idx", "iloc_ptr", "iloc_idx", "bloc_ptr", "bloc_idx"):
+            flat[k] = np.ascontiguousarray(flat[k], dtype=np.int64)
+            setattr(t, k, flat[k].ctypes.data_as(_lib.p_i64))
+        co = opts.to_c()
+        h = C.c_void_p()
+        self.L = _lib.lib()
+        _lib.check(self.L.hs_analyze(int(self.is_c), self.n, colptr.ctypes.data_as(_lib.p_i64), rowval.ctypes.data_as(_lib.p_i64),
+                                     C.byref(t), C.byref(co), self.rank, self.nranks, C.byref(h)))
+        self._h = h
+        ex = []
+        out6 = (C.c_int64 * 6)()
+        for k in range(self.L.hs_num_exchanges(h)):
+            _lib.check(self.L.hs_exchange_info(h, k, out6))
+            ex.append(dict(node=out6[0], level=out6[1], src=out6[2], dst=out6[3], nb=out6[4], nelems=out6[5]))
+        self.plan = Plan(self.L.hs_nlevels(h), self.L.hs_cut_level(h), ex, self.nranks)
+        # exchange buffers live in torch memory and are registered with the library
+        self._schur, self._bnd = {}, {}
+        for e in ex:
+            if self.rank in (e["src"], e["dst"]):
+                s = torch.zeros(max(int(e["nelems"]), 1), dtype=self.t_dtype, device=self.device)
+                _lib.check(self.L.hs_set_schur_buffer(h, e["node"], C.c_void_p(s.data_ptr())))
+                self._schur[e["node"]] = s
+                self._bnd[e["node"]] = torch.zeros(max(int(e["nb"]), 1), dtype=self.t_dtype, device=self.device)
+        self.values = torch.from_numpy(np.ascontiguousarray(A.data, dtype=self.np_dtype)).to(self.device)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self.L.hs_free(h)
+
+    # -- numeric --------------------------------------------------------------------------------------------
+    def set_values(self, values):
+        """New values for the same sparsity pattern (a torch tensor on this device, CSC order)."""
+        self.values = values
+
+    def numeric_begin(self):
+        _lib.check(self.L.hs_numeric_begin(self._h, C.c_void_p(self.values.data_ptr()), 1))
+
+    def numeric_levels(self, lv_from, lv_to):
+        _lib.check(self.L.hs_numeric_levels(self._h, lv_from, lv_to))
+
+    def numeric_end(self):
+        _lib.check(self.L.hs_numeric_end(self._h))
+
+    def schur_tensor(self, node):
+        return self._schur[node]
+
+    def sync(self):
+        """Library stream -> host: data the library produced is complete before the communicator reads it."""
+        self.torch.cuda.synchronize(self.device)
+
+    def comm_sync(self):
+        """Communicator -> host: received data is complete before the library's stream reads it."""
+        self.torch.cuda.synchronize(self.device)
+
+    # -- solve ------------------------------------------------------------------------------------------------
+    def _p(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    def fwd(self, b, lv_from, lv_to):
+        _lib.check(self.L.hs_solve_fwd_levels(self._h, self._p(b), lv_from, lv_to, self._stream()))
+
+    def bwd(self, b, lv_from, lv_to):
+        _lib.check(self.L.hs_solve_bwd_levels(self._h, self._p(b), lv_from, lv_to, self._stream()))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def pack_bnd(self, node, b):
+        buf = self._bnd[node]
+        _lib.check(self.L.hs_pack_bnd(self._h, node, self._p(b), self._p(buf), self._stream()))
+        return buf
+
+    def bnd_buffer(self, node):
+        return self._bnd[node]
+
+    def unpack_bnd(self, node, b, buf):
+        _lib.check(self.L.hs_unpack_bnd(self._h, node, self._p(b), self._p(buf), self._stream()))
+
+    def extract_owned(self, b):
+        out = self.torch.zeros_like(b)
+        _lib.check(self.L.hs_extract_owned(self._h, self._p(b), self._p(out), self._stream()))
+        return out
+
+    def assign(self, b, out):
+        b.copy_(out)
+
+    def stats(self):
+        st = _lib.hs_stats()
+        _lib.check(self.L.hs_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+
+class StagedSolver:
+    """analyze once, then ``numeric()`` / ``solve(b)`` with everything resident in HBM."""
+
+    def __init__(self, A, nd, nd_loc, opts=None, rank=0, nranks=1, comm=None, device=None, **kw):
+        self.backend = HipBackend(A, nd, nd_loc, opts, rank, nranks, device, **kw)
+        self.plan = self.backend.plan
+        self.rank = rank
+        self.comm = comm if comm is not None else (_NullComm() if nranks == 1 else TorchComm())
+
+    def numeric(self, values=None):
+        if values is not None:
+            self.backend.set_values(values)
+        run_numeric(self.backend, self.plan, self.rank, self.comm)
+
+    def solve(self, b):
+        """In place on a device tensor ``b`` of length n (every rank passes the same right-hand side)."""
+        return run_solve(self.backend, self.plan, self.rank, self.comm, b)
+
+    def stats(self):
+        return self.backend.stats()

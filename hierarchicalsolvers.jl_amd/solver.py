@@ -31,7 +31,7 @@ class SolverOptions:
     ``5, 1, 1e-6, 1e-6, 0.5, 32, -1, 10, false`` (HierarchicalSolvers.jl:43-54)."""
 
     _fields = ("swlevel", "swsize", "atol", "rtol", "c_tol", "leafsize", "kest", "stepsize", "verbose")
-    _ext = ("keep_schur", "seed")
+    _ext = ("keep_schur", "seed", "profile")
 
     def __init__(self, **kw):
         self.swlevel, self.swsize = 5, 1
@@ -39,6 +39,7 @@ class SolverOptions:
         self.leafsize, self.kest, self.stepsize = 32, -1, 10
         self.verbose = False
         self.keep_schur = False
+        self.profile = False
         self.seed = 123
         self._set(kw)
 
@@ -63,6 +64,7 @@ class SolverOptions:
         o.leafsize, o.kest, o.stepsize = int(self.leafsize), int(self.kest), int(self.stepsize)
         o.verbose = 1 if self.verbose else 0
         o.keep_schur = 1 if self.keep_schur else 0
+        o.profile = 1 if self.profile else 0
         o.seed = int(self.seed)
         return o
 

@@ -55,7 +55,8 @@ typedef struct hs_options {
   uint8_t verbose;
   /* ---- extensions ---- */
   uint8_t keep_schur; /* debug: retain every node's Schur complement S for hs_node_export */
-  uint8_t reserved[6];
+  uint8_t profile;    /* time every kernel launch with HIP events (fills hs_stats.t_gemm etc.; adds launch gaps) */
+  uint8_t reserved[5];
   int64_t seed;       /* RNG seed of the randomized compression (reference: Random.seed!(123), test/rungmres.jl:7) */
 } hs_options;
 
@@ -103,6 +104,38 @@ int hs_ldiv_z(hs_handle* F, double* C, int64_t ldc, const double* B, int64_t ldb
  * for an on-device Krylov caller (gmres(...; Pr=F), test/rungmres.jl:47-48). */
 int hs_ldiv_dev_d(hs_handle* F, double* dC, int64_t ldc, const double* dB, int64_t ldb, int64_t n, int64_t nrhs, void* stream);
 int hs_ldiv_dev_z(hs_handle* F, double* dC, int64_t ldc, const double* dB, int64_t ldb, int64_t n, int64_t nrhs, void* stream);
+
+/* ---- phased form of factor (hs_factor_* = hs_analyze + hs_numeric_* over all levels) -------------------------
+ * hs_analyze builds the plan and uploads the sparsity pattern, so a later numeric factorization starts with
+ * every input resident in HBM; the pattern (colptr, rowval, tree) is reused for new values of A.
+ * rank / nranks (a power of two): with nranks > 1 the 2^p subtrees rooted at tree level p+1 go one per rank
+ * (factorization.jl:20-21 factors them one after the other; they are independent), and a front above the cut
+ * is eliminated by the first rank of its group.  The library moves no data between ranks: the host layer does,
+ * with its own communication library (torch.distributed / RCCL here, MPI.jl for a Julia host), using
+ * hs_exchange_info for WHAT crosses ranks and hs_set_schur_buffer / hs_pack_bnd / hs_unpack_bnd for WHERE. */
+int hs_analyze(int is_complex, int64_t n, const int64_t* colptr, const int64_t* rowval, const hs_tree* tree,
+               const hs_options* opts, int64_t rank, int64_t nranks, hs_handle** out);
+int hs_numeric_begin(hs_handle* F, const void* nzval, int nzval_on_device);
+int hs_numeric_levels(hs_handle* F, int64_t level_from, int64_t level_to); /* deepest-first: from >= to; root = 1 */
+int hs_numeric_end(hs_handle* F); /* synchronise; HS_ERR_SINGULAR if a front hit an exactly zero pivot */
+
+/* sweeps of ldiv! on a device vector b (n elements of T), restricted to a range of tree levels */
+int hs_solve_fwd_levels(hs_handle* F, void* d_b, int64_t level_from, int64_t level_to, void* stream); /* from >= to */
+int hs_solve_bwd_levels(hs_handle* F, void* d_b, int64_t level_from, int64_t level_to, void* stream); /* from <= to */
+
+int64_t hs_nlevels(const hs_handle* F);   /* depth(nd) */
+int64_t hs_cut_level(const hs_handle* F); /* levels > cut are rank-local; 1 when nranks == 1 */
+int64_t hs_node_owner(const hs_handle* F, int64_t node);
+int64_t hs_num_exchanges(const hs_handle* F);
+/* out6 = {node, level of node, src rank, dst rank, nb, elements of T in the node's Schur buffer (lds*nb)}:
+ * node's Schur complement goes src -> dst before dst eliminates node's parent; in ldiv! the vector b[bnd(node)]
+ * goes src -> dst in the forward sweep and dst -> src in the backward sweep. */
+int hs_exchange_info(const hs_handle* F, int64_t k, int64_t* out6);
+/* make `dptr` (device memory owned by the caller, hs_exchange_info's element count) the node's Schur buffer */
+int hs_set_schur_buffer(hs_handle* F, int64_t node, void* dptr);
+int hs_pack_bnd(const hs_handle* F, int64_t node, const void* d_b, void* d_buf, void* stream);   /* buf[j] = b[bnd_j] */
+int hs_unpack_bnd(const hs_handle* F, int64_t node, void* d_b, const void* d_buf, void* stream); /* b[bnd_j] = buf[j] */
+int hs_extract_owned(const hs_handle* F, const void* d_b, void* d_out, void* stream); /* out[int(mine)] = b[int(mine)] */
 
 int64_t hs_maxrank(const hs_handle* F); /* factornode.jl:49-57; 0 for the dense path */
 int hs_is_complex(const hs_handle* F);  /* eltype(F) == ComplexF64 */
