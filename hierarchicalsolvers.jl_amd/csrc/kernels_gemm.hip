@@ -78,8 +78,7 @@ __device__ inline bool resolve_op(const NodeDesc<T>* pn, const GemmOp& op, GemmP
 template <int BN_>
 __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int tile_n, bool minus, double* smem) {
   constexpr int BN = BN_;  // 128
-  double* As = smem;                 // [BK][LDS_LD]
-  double* Bs = smem + BK * LDS_LD;   // [BK][LDS_LD]
+  constexpr int STAGE = 2 * BK * LDS_LD;  // one LDS stage: As [BK][LDS_LD] then Bs [BK][LDS_LD]; two stages
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
@@ -96,39 +95,43 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
 
   double2_u ra[4], rb[4];
 
+  // Global -> register staging.  Interior tiles take 16-byte loads with no guards.  Edge tiles use
+  // clamped 8-byte loads + selects: a per-lane `if (in range) load` compiles to a branch with an
+  // s_waitcnt vmcnt(0) at every join, i.e. eight fully serialised memory round trips per K-step
+  // (that cost 33 % of every wave's life in SQ_WAIT_ANY before this was restructured).
+  const bool interior = (m0 + BM <= M) && (n0 + BN <= N);
   auto load_tile = [&](int k0) {
+    if (interior && k0 + BK <= K) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int kk = k0 + a_k + 4 * i;
-      int mm = m0 + 2 * a_pair;
-      double2_u v = {0.0, 0.0};
-      if (kk < K) {
-        const double* src = A + (size_t)mm + (size_t)kk * p.lda;
-        if (mm + 1 < M) {
-          v = *reinterpret_cast<const double2_u*>(src);
-        } else if (mm < M) {
-          v.x = src[0];
-        }
-      }
-      ra[i] = v;
-    }
+      for (int i = 0; i < 4; ++i)
+        ra[i] = *reinterpret_cast<const double2_u*>(A + (size_t)(m0 + 2 * a_pair) + (size_t)(k0 + a_k + 4 * i) * p.lda);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int nn = n0 + b_n + 32 * i;
-      int kk = k0 + 2 * b_kp;
-      double2_u v = {0.0, 0.0};
-      if (nn < N) {
-        const double* src = B + (size_t)kk + (size_t)nn * p.ldb;
-        if (kk + 1 < K) {
-          v = *reinterpret_cast<const double2_u*>(src);
-        } else if (kk < K) {
-          v.x = src[0];
-        }
+      for (int i = 0; i < 4; ++i)
+        rb[i] = *reinterpret_cast<const double2_u*>(B + (size_t)(k0 + 2 * b_kp) + (size_t)(n0 + b_n + 32 * i) * p.ldb);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kk = k0 + a_k + 4 * i, mm = m0 + 2 * a_pair;
+        const double* col = A + (size_t)min(kk, K - 1) * p.lda;
+        double x = col[min(mm, M - 1)], y = col[min(mm + 1, M - 1)];
+        const bool kok = kk < K;
+        ra[i].x = (kok && mm < M) ? x : 0.0;
+        ra[i].y = (kok && mm + 1 < M) ? y : 0.0;
       }
-      rb[i] = v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int nn = n0 + b_n + 32 * i, kk = k0 + 2 * b_kp;
+        const double* col = B + (size_t)min(nn, N - 1) * p.ldb;
+        double x = col[min(kk, K - 1)], y = col[min(kk + 1, K - 1)];
+        const bool nok = nn < N;
+        rb[i].x = (nok && kk < K) ? x : 0.0;
+        rb[i].y = (nok && kk + 1 < K) ? y : 0.0;
+      }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int stage) {
+    double* As = smem + stage * STAGE;
+    double* Bs = As + BK * LDS_LD;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       double* dst = As + (a_k + 4 * i) * LDS_LD + 2 * a_pair;
@@ -150,53 +153,83 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
   const int l15 = lane & 15, l4 = lane >> 4;
-  const double* a_rd = As + l4 * LDS_LD + wm * 64 + l15;
-  const double* b_rd = Bs + l4 * LDS_LD + wn * 64 + l15;
+  const int a_off = l4 * LDS_LD + wm * 64 + l15;
+  const int b_off = BK * LDS_LD + l4 * LDS_LD + wn * 64 + l15;
 
+  // Two LDS stages, ONE barrier per K-step: while the MFMAs of stage `cur` run, the next tile's global
+  // loads are in flight; they are written to the other stage right after the MFMAs (every wave finished
+  // reading that stage before the previous barrier).
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
+  int cur = 0;
   for (int k0 = 0; k0 < K; k0 += BK) {
     const bool more = (k0 + BK) < K;
     if (more) load_tile(k0 + BK);
+    const double* a_rd = smem + cur * STAGE + a_off;
+    const double* b_rd = smem + cur * STAGE + b_off;
+    // Chained issue: v_mfma_f64_16x16x4_f64 pays ~40 extra cycles whenever consecutive MFMAs use a
+    // different accumulator (C read + D write through the register file); back-to-back MFMAs on the
+    // SAME accumulator forward it inside the pipe (measured: 105 -> 74 cycles/MFMA at chain 4,
+    // tools/mfma_f64_probe.hip).  So every accumulator takes all BK/4 k-steps of the tile in a row.
+    {
+      double bf[4][BK / 4];
 #pragma unroll
-    for (int ks = 0; ks < BK; ks += 4) {
-      double af[4], bf[4];
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = a_rd[ks * LDS_LD + i * 16];
+        for (int ks = 0; ks < BK / 4; ++ks) bf[j][ks] = b_rd[(ks * 4) * LDS_LD + j * 16];
+      double af[BK / 4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = b_rd[ks * LDS_LD + j * 16];
+      for (int ks = 0; ks < BK / 4; ++ks) af[ks] = a_rd[(ks * 4) * LDS_LD];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        double afn[BK / 4];
+        if (i < 3) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          // transposed issue: MFMA-A <- B data (n on the register/row axis), MFMA-B <- A data (m on lane&15)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-    if (more) {
-      store_tile();
-      __syncthreads();
-    }
-  }
-
-  // epilogue: acc[i][j][r] <-> C[m0 + wm*64 + i*16 + l15][n0 + wn*64 + j*16 + l4 + 4r]
-  double* __restrict__ C = p.C;
+          for (int ks = 0; ks < BK / 4; ++ks) afn[ks] = a_rd[(ks * 4) * LDS_LD + (i + 1) * 16];
+        }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int mm = m0 + wm * 64 + i * 16 + l15;
-    if (mm >= M) continue;
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+          for (int ks = 0; ks < BK / 4; ++ks)
+            // transposed issue: MFMA-A <- B data (n on the register/row axis), MFMA-B <- A data (m on lane&15)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j][ks], af[ks], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);  // keep the chain together: the scheduler must not interleave accumulators
+        }
+        if (i < 3) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int nn = n0 + wn * 64 + j * 16 + l4 + 4 * r;
-        if (nn < N) {
-          double* c = C + (size_t)mm + (size_t)nn * p.ldc;
-          *c = minus ? (*c - acc[i][j][r]) : acc[i][j][r];
+          for (int ks = 0; ks < BK / 4; ++ks) af[ks] = afn[ks];
         }
       }
     }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: acc[i][j][r] <-> C[m0 + wm*64 + i*16 + l15][n0 + wn*64 + j*16 + l4 + 4r].
+  // All 16 loads of a row block are issued before the first store (the compiler cannot prove the C
+  // addresses distinct and would otherwise serialise load -> store -> load ...).
+  double* __restrict__ C = p.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mm = m0 + wm * 64 + i * 16 + l15;
+    const bool rok = mm < M;
+    double cv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n0 + wn * 64 + j * 16 + l4 + 4 * r;
+        cv[j][r] = (minus && rok && nn < N) ? C[(size_t)mm + (size_t)nn * p.ldc] : 0.0;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n0 + wn * 64 + j * 16 + l4 + 4 * r;
+        if (rok && nn < N) C[(size_t)mm + (size_t)nn * p.ldc] = minus ? (cv[j][r] - acc[i][j][r]) : acc[i][j][r];
+      }
   }
 }
 
@@ -224,20 +257,23 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
   const int b_k = tid & 15, b_n = tid >> 4;
   double2_u ra[8], rb[4];
 
+  // branch-free staging (clamped address + select), see gemm_tile_d
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      int kk = k0 + a_k + 2 * i, mm = m0 + a_m;
-      double2_u v = {0.0, 0.0};
-      if (kk < K && mm < M) v = *reinterpret_cast<const double2_u*>(A + (size_t)mm + (size_t)kk * p.lda);
-      ra[i] = v;
+      const int kk = k0 + a_k + 2 * i, mm = m0 + a_m;
+      double2_u v = *reinterpret_cast<const double2_u*>(A + (size_t)min(mm, M - 1) + (size_t)min(kk, K - 1) * p.lda);
+      const bool ok = kk < K && mm < M;
+      ra[i].x = ok ? v.x : 0.0;
+      ra[i].y = ok ? v.y : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int kk = k0 + b_k, nn = n0 + b_n + 16 * i;
-      double2_u v = {0.0, 0.0};
-      if (kk < K && nn < N) v = *reinterpret_cast<const double2_u*>(B + (size_t)kk + (size_t)nn * p.ldb);
-      rb[i] = v;
+      const int kk = k0 + b_k, nn = n0 + b_n + 16 * i;
+      double2_u v = *reinterpret_cast<const double2_u*>(B + (size_t)min(kk, K - 1) + (size_t)min(nn, N - 1) * p.ldb);
+      const bool ok = kk < K && nn < N;
+      rb[i].x = ok ? v.x : 0.0;
+      rb[i].y = ok ? v.y : 0.0;
     }
   };
   auto store_tile = [&]() {
@@ -273,29 +309,39 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
   for (int k0 = 0; k0 < K; k0 += BK) {
     const bool more = (k0 + BK) < K;
     if (more) load_tile(k0 + BK);
+    {  // chained issue, see gemm_tile_d: each accumulator takes its 2 * BK/4 MFMAs back to back
+      double bfr[2][BK / 4], bfi[2][BK / 4];
 #pragma unroll
-    for (int ks = 0; ks < BK; ks += 4) {
-      double afr[4], afi[4], bfr[2], bfi[2], bfin[2];
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+          bfr[j][ks] = Br[b_off + (ks * 4) * ZLDB + j * 16];
+          bfi[j][ks] = Bi[b_off + (ks * 4) * ZLDB + j * 16];
+        }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        afr[i] = Ar[a_off + ks * LDS_LD + i * 16];
-        afi[i] = Ai[a_off + ks * LDS_LD + i * 16];
-      }
+        double afr[BK / 4], afi[BK / 4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bfr[j] = Br[b_off + ks * ZLDB + j * 16];
-        bfi[j] = Bi[b_off + ks * ZLDB + j * 16];
-        bfin[j] = -bfi[j];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int ks = 0; ks < BK / 4; ++ks) {
+          afr[ks] = Ar[a_off + (ks * 4) * LDS_LD + i * 16];
+          afi[ks] = Ai[a_off + (ks * 4) * LDS_LD + i * 16];
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[j], afr[i], accr[i][j], 0, 0, 0);
-          accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfin[j], afi[i], accr[i][j], 0, 0, 0);
-          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfi[j], afr[i], acci[i][j], 0, 0, 0);
-          acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[j], afi[i], acci[i][j], 0, 0, 0);
+#pragma unroll
+          for (int ks = 0; ks < BK / 4; ++ks) {
+            accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[j][ks], afr[ks], accr[i][j], 0, 0, 0);
+            accr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfi[j][ks], afi[ks], accr[i][j], 0, 0, 1);  // blgp bit 0 = NEG(src A) on f64 MFMA: re -= bi*ai
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < BK / 4; ++ks) {
+            acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfi[j][ks], afr[ks], acci[i][j], 0, 0, 0);
+            acci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[j][ks], afi[ks], acci[i][j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
+      }
     }
     __syncthreads();
     if (more) {
@@ -306,22 +352,30 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
   cplx* __restrict__ C = p.C;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int mm = m0 + wm * 64 + i * 16 + l15;
-    if (mm >= M) continue;
+    const int mm = m0 + wm * 64 + i * 16 + l15;
+    const bool rok = mm < M;
+    double2_u cv[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int nn = n0 + wn * 32 + j * 16 + l4 + 4 * r;
-        if (nn < N) {
-          double2_u* c = reinterpret_cast<double2_u*>(C + (size_t)mm + (size_t)nn * p.ldc);
+        const int nn = n0 + wn * 32 + j * 16 + l4 + 4 * r;
+        double2_u o = {0.0, 0.0};
+        if (minus && rok && nn < N) o = *reinterpret_cast<const double2_u*>(C + (size_t)mm + (size_t)nn * p.ldc);
+        cv[j][r] = o;
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n0 + wn * 32 + j * 16 + l4 + 4 * r;
+        if (rok && nn < N) {
           double2_u v = {accr[i][j][r], acci[i][j][r]};
           if (minus) {
-            double2_u o = *c;
-            v.x = o.x - v.x;
-            v.y = o.y - v.y;
+            v.x = cv[j][r].x - v.x;
+            v.y = cv[j][r].y - v.y;
           }
-          *c = v;
+          *reinterpret_cast<double2_u*>(C + (size_t)mm + (size_t)nn * p.ldc) = v;
         }
       }
   }
@@ -332,7 +386,7 @@ struct TileCfg;
 template <>
 struct TileCfg<double> {
   static constexpr int bn = 128;
-  static constexpr int smem_doubles = 2 * BK * LDS_LD;
+  static constexpr int smem_doubles = 2 * (2 * BK * LDS_LD);  // two stages
 };
 template <>
 struct TileCfg<cplx> {
@@ -340,8 +394,17 @@ struct TileCfg<cplx> {
   static constexpr int smem_doubles = 2 * BK * LDS_LD + 2 * BK * ZLDB;
 };
 
+// Two workgroups share a CU (one wave of each per SIMD).  Started together they run in lockstep: all
+// eight waves stage/barrier at the same moments and the MFMA pipe idles ~40 % (SQ_VALU_MFMA_BUSY_CYCLES
+// 59 %, SQ_WAIT_ANY 33 % on 8192^3).  Delaying every second workgroup of a CU by about half a K-step
+// lets one wave's MFMAs cover the other's staging.  Placement-dependent for speed only.
+__device__ int g_gemm_stagger = 0;
+
 template <class T>
 __device__ inline void gemm_dispatch(const GemmProb<T>& p, bool minus, double* smem) {
+  if (g_gemm_stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+    for (int i = 0; i < g_gemm_stagger; ++i) __builtin_amdgcn_s_sleep(8);  // 8 * 64 cycles
+  }
   int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + TileCfg<T>::bn - 1) / TileCfg<T>::bn;
   int ntiles = tiles_m * tiles_n;
   if ((int)blockIdx.x >= ntiles) return;
@@ -356,7 +419,7 @@ __device__ inline void gemm_dispatch(const GemmProb<T>& p, bool minus, double* s
 
 template <class T>
 __global__ __launch_bounds__(256, 2) void gemm_op_kernel(const NodeDesc<T>* __restrict__ nodes, GemmOp op) {
-  __shared__ double smem[TileCfg<T>::smem_doubles];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   GemmProb<T> p;
   if (!resolve_op(nodes + blockIdx.y, op, p)) return;
   gemm_dispatch<T>(p, true, smem);
@@ -364,11 +427,13 @@ __global__ __launch_bounds__(256, 2) void gemm_op_kernel(const NodeDesc<T>* __re
 
 template <class T>
 __global__ __launch_bounds__(256, 2) void gemm_probs_kernel(const GemmProb<T>* __restrict__ probs, int minus) {
-  __shared__ double smem[TileCfg<T>::smem_doubles];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   GemmProb<T> p = probs[blockIdx.y];
   if (p.M <= 0 || p.N <= 0) return;
   gemm_dispatch<T>(p, minus != 0, smem);
 }
+
+static void set_stagger_once();
 
 template <class T>
 __global__ void resolve_dump_kernel(const NodeDesc<T>* __restrict__ nodes, GemmOp op, GemmProb<T>* out, int* ok) {
@@ -409,14 +474,37 @@ void launch_gemm_op(const NodeDesc<T>* dnodes, int nbatch, int maxM, int maxN, c
       (void)hipFree(dok);
     }
   }
+  set_stagger_once();
   int tiles = ((maxM + BM - 1) / BM) * ((maxN + TileCfg<T>::bn - 1) / TileCfg<T>::bn);
-  hipLaunchKernelGGL(gemm_op_kernel<T>, dim3(tiles, nbatch), dim3(256), 0, s, dnodes, op);
+  constexpr int lds_bytes = TileCfg<T>::smem_doubles * 8;
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KiB of LDS per workgroup needs the opt-in
+    (void)hipFuncSetAttribute((const void*)gemm_op_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_op_kernel<T>, dim3(tiles, nbatch), dim3(256), lds_bytes, s, dnodes, op);
 }
+static void set_stagger_once() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const char* e = getenv("HS_GEMM_STAGGER");
+  int v = e ? atoi(e) : 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stagger), &v, sizeof v);
+}
+
 template <class T>
 void launch_gemm_probs(const GemmProb<T>* dprobs, int nprob, int maxM, int maxN, int minus, hipStream_t s) {
   if (nprob <= 0 || maxM <= 0 || maxN <= 0) return;
+  set_stagger_once();
   int tiles = ((maxM + BM - 1) / BM) * ((maxN + TileCfg<T>::bn - 1) / TileCfg<T>::bn);
-  hipLaunchKernelGGL(gemm_probs_kernel<T>, dim3(tiles, nprob), dim3(256), 0, s, dprobs, minus);
+  constexpr int lds_bytes = TileCfg<T>::smem_doubles * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_probs_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_probs_kernel<T>, dim3(tiles, nprob), dim3(256), lds_bytes, s, dprobs, minus);
 }
 
 template void launch_gemm_op<double>(const NodeDesc<double>*, int, int, int, const GemmOp&, hipStream_t);
