@@ -100,10 +100,11 @@ enum { HS_MAT_LF = 0, HS_MAT_UR = 1, HS_MAT_SB = 2 };
 // Sub-block op of the recursive LU on a batch of fronts: ranges are given in front coordinates and
 // clipped per node to the extents of the matrices they address.
 struct GemmOp {
-  int cmat, bmat;  // C and B live in LF / UR / SB; A is always LF
+  int cmat, bmat;  // C and B live in LF / UR / SB; A is LF (or a stored inverse diagonal block, see ainv)
   int r0, r1;      // C rows   (A rows are the same, shifted by ni when C is SB)
   int c0, c1;      // C cols = B cols
   int k0, k1;      // A cols = B rows (always inside [0, ni))
+  int ainv;        // 1: A = invL[r0/32] (32x32), C = A*B in place on rows [r0, r0+32): the TRSM base case
 };
 
 // plain problem (test hooks, root Schur, compressed path)

@@ -80,7 +80,7 @@ struct Sched {
   int cols_of(int mat) const { return mat == HS_MAT_LF ? maxni : maxnb; }
 
   void gemm(int cmat, int bmat, int r0, int r1, int c0, int c1, int k0, int k1) {
-    GemmOp op{cmat, bmat, r0, r1, c0, c1, k0, k1};
+    GemmOp op{cmat, bmat, r0, r1, c0, c1, k0, k1, 0};
     int M = std::min(r1, rows_of(cmat)) - r0, N = std::min(c1, cols_of(cmat)) - c0, K = std::min(k1, maxni) - k0;
     if (M <= 0 || N <= 0 || K <= 0) return;
     double fl = 0.0;
@@ -130,8 +130,10 @@ struct Sched {
     int nc = std::min(c1, cols_of(mat)) - c0;
     if (nc <= 0) return;
     if (r1 - r0 == HS_PB) {
+      // base case: multiply by the stored inverse of the 32x32 unit-lower diagonal block (MFMA GEMM, in place)
+      GemmOp op{mat, mat, r0, r0 + HS_PB, c0, c1, 0, 0, 1};
       hipEvent_t e0 = pf->begin(s);
-      launch_trsm_blk<T>(dn, nbatch, mat, r0, c0, c1, nc, s);
+      launch_gemm_op<T>(dn, nbatch, HS_PB, nc, op, s);
       pf->end(e0, HS_CAT_TRSM, s);
       dbg("trsm_blk", mat, r0, c0, c1);
       return;

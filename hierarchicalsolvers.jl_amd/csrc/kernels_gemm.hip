@@ -29,6 +29,7 @@ typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));  // 16
 
 #define BM 128
 #define BK 16
+#define LDB_S 18   // B image is [n][k] with 16 + 2 padding: ds_write_b128 of a k-pair row segment and the MFMA-operand ds_read_b64 are both conflict-free
 #define LDS_LD 144  // 128 + 16: stride == 16 (mod 32) doubles => conflict-free ds_read_b64 across the two k rows of a half-wave
 
 // bijective XCD-aware remap of a 1-D block id (cdna guide section 5, "XCD swizzle must be bijective"):
@@ -60,6 +61,17 @@ __device__ inline bool resolve_op(const NodeDesc<T>* pn, const GemmOp& op, GemmP
   mat_of(pn, op.bmat, bp, ldb, brows, bcols);
   const int ni = pn->ni, ldl = pn->ldl;
   T* const LF = pn->LF;
+  if (op.ainv) {  // X[r0:r0+w, c0:c1) <- inv(L11[r0/32]) * X, in place (one tile row, all of K is read before the stores)
+    const int w = min(HS_PB, ni - op.r0);
+    const int N = min(op.c1, ccols) - op.c0;
+    if (w <= 0 || N <= 0) return false;
+    p.A = pn->invL + (size_t)(op.r0 / HS_PB) * HS_PB * HS_PB;
+    p.B = cp + (size_t)op.r0 + (size_t)op.c0 * ldc;
+    p.C = cp + (size_t)op.r0 + (size_t)op.c0 * ldc;
+    p.M = w; p.N = N; p.K = w;
+    p.lda = HS_PB; p.ldb = ldc; p.ldc = ldc;
+    return true;
+  }
   int r1 = min(op.r1, crows), c1 = min(op.c1, ccols), k1 = min(op.k1, ni);
   int M = r1 - op.r0, N = c1 - op.c0, K = k1 - op.k0;
   if (M <= 0 || N <= 0 || K <= 0) return false;
@@ -140,9 +152,9 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int nn = b_n + 32 * i;
-      Bs[(2 * b_kp) * LDS_LD + nn] = rb[i].x;
-      Bs[(2 * b_kp + 1) * LDS_LD + nn] = rb[i].y;
+      double* dst = Bs + (b_n + 32 * i) * LDB_S + 2 * b_kp;  // 16-byte aligned: 144 n + 16 kp bytes
+      dst[0] = rb[i].x;
+      dst[1] = rb[i].y;
     }
   };
 
@@ -154,7 +166,7 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
 
   const int l15 = lane & 15, l4 = lane >> 4;
   const int a_off = l4 * LDS_LD + wm * 64 + l15;
-  const int b_off = BK * LDS_LD + l4 * LDS_LD + wn * 64 + l15;
+  const int b_off = BK * LDS_LD + (wn * 64 + l15) * LDB_S + l4;
 
   // Two LDS stages, ONE barrier per K-step: while the MFMAs of stage `cur` run, the next tile's global
   // loads are in flight; they are written to the other stage right after the MFMAs (every wave finished
@@ -177,7 +189,7 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) bf[j][ks] = b_rd[(ks * 4) * LDS_LD + j * 16];
+        for (int ks = 0; ks < BK / 4; ++ks) bf[j][ks] = b_rd[(j * 16) * LDB_S + ks * 4];
       double af[BK / 4];
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) af[ks] = a_rd[(ks * 4) * LDS_LD];
@@ -237,12 +249,12 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
 // complex double (planar split in LDS)
 // ------------------------------------------------------------------------------------------------
 #define ZBN 64
-#define ZLDB 80  // 64 + 16
+#define ZLDB 18  // B images are [n][k], 16 + 2 padding (see LDB_S)
 __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile_n, bool minus, double* smem) {
   double* Ar = smem;
   double* Ai = Ar + BK * LDS_LD;
   double* Br = Ai + BK * LDS_LD;
-  double* Bi = Br + BK * ZLDB;
+  double* Bi = Br + ZBN * ZLDB;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
@@ -285,7 +297,7 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int o = b_k * ZLDB + b_n + 16 * i;
+      int o = (b_n + 16 * i) * ZLDB + b_k;
       Br[o] = rb[i].x;
       Bi[o] = rb[i].y;
     }
@@ -301,7 +313,7 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
     }
   const int l15 = lane & 15, l4 = lane >> 4;
   const int a_off = l4 * LDS_LD + wm * 64 + l15;
-  const int b_off = l4 * ZLDB + wn * 32 + l15;
+  const int b_off = (wn * 32 + l15) * ZLDB + l4;
 
   load_tile(0);
   store_tile();
@@ -315,8 +327,8 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
-          bfr[j][ks] = Br[b_off + (ks * 4) * ZLDB + j * 16];
-          bfi[j][ks] = Bi[b_off + (ks * 4) * ZLDB + j * 16];
+          bfr[j][ks] = Br[b_off + (j * 16) * ZLDB + ks * 4];
+          bfi[j][ks] = Bi[b_off + (j * 16) * ZLDB + ks * 4];
         }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -391,7 +403,7 @@ struct TileCfg<double> {
 template <>
 struct TileCfg<cplx> {
   static constexpr int bn = ZBN;
-  static constexpr int smem_doubles = 2 * BK * LDS_LD + 2 * BK * ZLDB;
+  static constexpr int smem_doubles = 2 * BK * LDS_LD + 2 * ZBN * ZLDB;
 };
 
 // Two workgroups share a CU (one wave of each per SIMD).  Started together they run in lockstep: all
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void gemm_op_kernel(const NodeDesc<T>* __re
   extern __shared__ __attribute__((aligned(16))) double smem[];
   GemmProb<T> p;
   if (!resolve_op(nodes + blockIdx.y, op, p)) return;
-  gemm_dispatch<T>(p, true, smem);
+  gemm_dispatch<T>(p, op.ainv == 0, smem);
 }
 
 template <class T>

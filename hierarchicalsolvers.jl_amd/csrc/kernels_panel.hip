@@ -22,19 +22,36 @@
 #include "hs_common.h"
 
 // ------------------------------------------------------------------------------------------------
-// argmax of (key, idx) over a 256-thread block; ties -> smallest idx.  Returns idx of the max key
-// (key < 0 means "not a candidate"; result -1 if no candidate has key > 0).
+// Pivot search: max over the 256 rows of a chunk of a 64-bit key = |a_k| bits with the low 8 bits
+// replaced by 255 - thread id (so ties, and values equal to 44 mantissa bits, go to the lowest row).
+// In-wave: 4 DPP steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) + 4 readlanes, no LDS;
+// across the 4 waves: one LDS slot each and ONE barrier per elimination step.
 // ------------------------------------------------------------------------------------------------
-__device__ inline void wave_argmax(double& key, int& idx) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double ok = __shfl_xor(key, off, 64);
-    int oi = __shfl_xor(idx, off, 64);
-    if (ok > key || (ok == key && oi < idx)) {
-      key = ok;
-      idx = oi;
-    }
+__device__ inline unsigned long long dpp_max_u64(unsigned long long v, const int ctrl_sel) {
+  int lo = (int)(unsigned)(v & 0xffffffffull), hi = (int)(unsigned)(v >> 32);
+  int olo, ohi;
+  switch (ctrl_sel) {
+    case 0: olo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); break;   // quad_perm [1,0,3,2]
+    case 1: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); break;   // quad_perm [2,3,0,1]
+    case 2: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); break; // row_half_mirror
+    default: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, false); break; // row_mirror
   }
+  unsigned long long o = ((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo;
+  return o > v ? o : v;
+}
+__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
+  v = dpp_max_u64(v, 0);
+  v = dpp_max_u64(v, 1);
+  v = dpp_max_u64(v, 2);
+  v = dpp_max_u64(v, 3);  // every row of 16 lanes now holds its maximum
+  int lo = (int)(unsigned)(v & 0xffffffffull), hi = (int)(unsigned)(v >> 32);
+  unsigned long long m = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    unsigned long long x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, 16 * r) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, 16 * r);
+    m = x > m ? x : m;
+  }
+  return m;
 }
 
 template <class T>
@@ -71,53 +88,39 @@ __global__ __launch_bounds__(HS_CHUNK) void tournament_kernel(const NodeDesc<T>*
     if (live && j < w) a[j] = nd.LF[(size_t)row + (size_t)(c0 + j) * nd.ldl];
   }
 
-  __shared__ T prow[HS_PB];
-  __shared__ double wkey[4];
-  __shared__ int widx[4];
-  __shared__ int s_win;
+  __shared__ T prow[2][HS_PB + 1];              // winner's row (+ reciprocal of the pivot), double-buffered by k parity
+  __shared__ unsigned long long wkey[2][4];     // per-wave maxima, double-buffered by k parity
 
 #pragma unroll
   for (int k = 0; k < HS_PB; ++k) {
     if (k < w) {
-      double key = live ? Scal<T>::abs1(a[k]) : -1.0;
-      int idx = t;
-      wave_argmax(key, idx);
-      if ((t & 63) == 0) {
-        wkey[t >> 6] = key;
-        widx[t >> 6] = idx;
-      }
+      unsigned long long key = 0;
+      if (live) key = ((unsigned long long)__double_as_longlong(Scal<T>::abs1(a[k])) & ~0xffull) | (unsigned long long)(255 - t);
+      unsigned long long wm = wave_max_u64(key);
+      if ((t & 63) == 0) wkey[k & 1][t >> 6] = wm;
       __syncthreads();
-      if (t == 0) {
-        double bk = wkey[0];
-        int bi = widx[0];
+      unsigned long long best = wkey[k & 1][0];
 #pragma unroll
-        for (int v = 1; v < 4; ++v)
-          if (wkey[v] > bk || (wkey[v] == bk && widx[v] < bi)) {
-            bk = wkey[v];
-            bi = widx[v];
-          }
-        s_win = (bk > 0.0) ? bi : -1;
-      }
-      __syncthreads();
-      const int win = s_win;
+      for (int v = 1; v < 4; ++v) best = wkey[k & 1][v] > best ? wkey[k & 1][v] : best;
+      const int win = ((best >> 8) != 0) ? 255 - (int)(best & 0xff) : -1;  // wave-uniform, identical in all waves
       if (win >= 0) {
         if (t == win) {
 #pragma unroll
-          for (int j = 0; j < HS_PB; ++j) prow[j] = a[j];
+          for (int j = 0; j < HS_PB; ++j) prow[k & 1][j] = a[j];
+          prow[k & 1][HS_PB] = Scal<T>::one() / a[k];
           cout[obase + k] = row;
           live = false;
         }
         __syncthreads();
         if (live) {
-          T l = a[k] / prow[k];
+          T l = a[k] * prow[k & 1][HS_PB];
 #pragma unroll
           for (int j = 0; j < HS_PB; ++j)
-            if (j > k) a[j] = Scal<T>::fnma(l, prow[j], a[j]);
+            if (j > k) a[j] = Scal<T>::fnma(l, prow[k & 1][j], a[j]);
         }
       } else {
         if (t == 0) cout[obase + k] = -1;  // column is exactly zero below the diagonal: singular
       }
-      __syncthreads();
     } else {
       if (t == 0) cout[obase + k] = -1;
     }
@@ -135,48 +138,41 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
   const int w = min(HS_PB, nd.ni - c0);
   const int t = threadIdx.x;
 
-  __shared__ int s_piv[HS_PB];            // swap target of row c0+k
-  __shared__ int s_pos[2 * HS_PB];        // positions touched so far
-  __shared__ int s_who[2 * HS_PB];        // original row now living at s_pos[i]
-  __shared__ T s_a[HS_PB][HS_PB + 1];     // [row][col]
+  __shared__ int s_piv[HS_PB];     // swap target of row c0+k
+  __shared__ int s_where[HS_PB];   // current position of the row that started at top position c0+i
+  __shared__ int s_what[HS_PB];    // row (by starting position) now sitting at top position c0+i
+  __shared__ T s_a[HS_PB][HS_PB + 1];   // [row][col]
   __shared__ T s_il[HS_PB][HS_PB + 1];
   __shared__ T s_iu[HS_PB][HS_PB + 1];
 
+  if (t < HS_PB) {
+    s_where[t] = c0 + t;
+    s_what[t] = c0 + t;
+  }
+  __syncthreads();
   if (t == 0) {
-    // winners (original row ids, in elimination order) -> sequential swaps.  Track which original
-    // row currently sits at every touched position.
-    int ntouch = 0;
+    // winners (rows by their position at panel start, in elimination order) -> LAPACK-style swaps.
+    // A row from below the top block sits where it started until it is picked; rows that started in
+    // the top block are tracked through `where`; positions c0+j, j < k, are final.
     for (int k = 0; k < w; ++k) {
-      int r = nd.pivlist[k];
-      int target = c0 + k;
-      int p;
-      if (r < 0) {
-        p = target;  // no pivot: leave the row, flag singular
+      const int r = nd.pivlist[k];
+      const int target = c0 + k;
+      int p = target;
+      if (r < 0) {  // no pivot: leave the row, flag the front singular
         int old = *nd.info;
         if (old == 0 || old > c0 + k + 1) *nd.info = c0 + k + 1;
       } else {
-        // current position of original row r
-        p = r;
-        for (int i = 0; i < ntouch; ++i)
-          if (s_who[i] == r) p = s_pos[i];
+        p = (r >= c0 && r < c0 + w) ? s_where[r - c0] : r;
       }
       s_piv[k] = p;
-      if (p != target) {
-        // who is at target now?
-        int qrow = target;
-        int it = -1, ip = -1;
-        for (int i = 0; i < ntouch; ++i) {
-          if (s_pos[i] == target) { qrow = s_who[i]; it = i; }
-        }
-        for (int i = 0; i < ntouch; ++i)
-          if (s_pos[i] == p) ip = i;
-        // after the swap: position target holds r, position p holds qrow
-        if (it < 0) { it = ntouch++; s_pos[it] = target; }
-        s_who[it] = r;
-        if (ip < 0) { ip = ntouch++; s_pos[ip] = p; }
-        s_who[ip] = qrow;
-      }
       nd.ipiv[c0 + k] = p;
+      if (p != target) {
+        const int q = s_what[k];  // always a row that started inside the top block
+        s_what[k] = r;
+        if (p >= c0 && p < c0 + w) s_what[p - c0] = q;
+        if (r >= c0 && r < c0 + w) s_where[r - c0] = target;
+        s_where[q - c0] = p;
+      }
     }
   }
   __syncthreads();
@@ -203,52 +199,52 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
     }
   }
   __syncthreads();
-  // load the top w x w block (identity-padded to 32)
+  // load the top w x w block (identity-padded to 32); il = iu = I
   for (int e = t; e < HS_PB * HS_PB; e += 256) {
     int i = e & 31, j = e >> 5;
-    T v = (i == j) ? Scal<T>::one() : Scal<T>::zero();
+    T id = (i == j) ? Scal<T>::one() : Scal<T>::zero();
+    T v = id;
     if (i < w && j < w) v = nd.LF[(size_t)(c0 + i) + (size_t)(c0 + j) * nd.ldl];
     s_a[i][j] = v;
+    s_il[i][j] = id;
+    s_iu[i][j] = id;
   }
   __syncthreads();
-  // unpivoted LU (pivot order fixed by the tournament)
+  // unpivoted LU (pivot order fixed by the tournament); the same row operations applied to I give inv(L)
   for (int k = 0; k < HS_PB; ++k) {
-    T piv = s_a[k][k];
-    bool zero_piv = (Scal<T>::abs1(piv) == 0.0);
+    const T piv = s_a[k][k];
+    const bool zero_piv = (Scal<T>::abs1(piv) == 0.0);
     if (t < HS_PB && t > k && !zero_piv) s_a[t][k] = s_a[t][k] / piv;
-    __syncthreads();
-    if (!zero_piv) {
-      for (int e = t; e < HS_PB * HS_PB; e += 256) {
-        int i = e & 31, j = e >> 5;
-        if (i > k && j > k) s_a[i][j] = Scal<T>::fnma(s_a[i][k], s_a[k][j], s_a[i][j]);
-      }
-    } else if (t == 0 && k < w) {
+    if (zero_piv && t == 0 && k < w) {
       int old = *nd.info;
       if (old == 0 || old > c0 + k + 1) *nd.info = c0 + k + 1;
     }
     __syncthreads();
-  }
-  // inverses of L (unit lower) and U (upper): thread j < 32 solves column j
-  if (t < HS_PB) {
-    const int j = t;
-    // L * x = e_j  (forward)
-    for (int i = 0; i < HS_PB; ++i) {
-      T s = (i == j) ? Scal<T>::one() : Scal<T>::zero();
-      for (int p = j; p < i; ++p) s = Scal<T>::fnma(s_a[i][p], s_il[p][j], s);
-      s_il[i][j] = (i < j) ? Scal<T>::zero() : s;
+    if (!zero_piv) {
+      for (int e = t; e < HS_PB * HS_PB; e += 256) {
+        int i = e & 31, j = e >> 5;
+        if (i > k) {
+          if (j > k)
+            s_a[i][j] = Scal<T>::fnma(s_a[i][k], s_a[k][j], s_a[i][j]);
+          else
+            s_il[i][j] = Scal<T>::fnma(s_a[i][k], s_il[k][j], s_il[i][j]);
+        }
+      }
     }
-  } else if (t >= 64 && t < 64 + HS_PB) {
-    const int j = t - 64;
-    // U * x = e_j  (backward); zero pivots are treated as 1 (front is already flagged singular)
-    for (int i = HS_PB - 1; i >= 0; --i) {
-      T s = (i == j) ? Scal<T>::one() : Scal<T>::zero();
-      for (int p = i + 1; p <= j; ++p) s = Scal<T>::fnma(s_a[i][p], s_iu[p][j], s);
-      T d = s_a[i][i];
-      if (Scal<T>::abs1(d) == 0.0) d = Scal<T>::one();
-      s_iu[i][j] = (i > j) ? Scal<T>::zero() : s / d;
-    }
+    __syncthreads();
   }
-  __syncthreads();
+  // inv(U) by back substitution in rank-1 form (zero pivots are treated as 1: the front is already flagged)
+  for (int p = HS_PB - 1; p >= 0; --p) {
+    T d = s_a[p][p];
+    if (Scal<T>::abs1(d) == 0.0) d = Scal<T>::one();
+    if (t < HS_PB && t >= p) s_iu[p][t] = s_iu[p][t] / d;
+    __syncthreads();
+    for (int e = t; e < HS_PB * HS_PB; e += 256) {
+      int i = e & 31, j = e >> 5;
+      if (i < p && j >= p) s_iu[i][j] = Scal<T>::fnma(s_a[i][p], s_iu[p][j], s_iu[i][j]);
+    }
+    __syncthreads();
+  }
   for (int e = t; e < HS_PB * HS_PB; e += 256) {
     int i = e & 31, j = e >> 5;
     if (i < w && j < w) nd.LF[(size_t)(c0 + i) + (size_t)(c0 + j) * nd.ldl] = s_a[i][j];
