@@ -13,3 +13,4 @@ from . import problems  # noqa: F401
 from .solver import SolverOptions, chkopts, factor, factorize, FactorNode, ldiv, maxrank  # noqa: F401,E402
 from ._lib import DimensionMismatch, SingularException, DeviceError, UnsupportedError  # noqa: F401,E402
 from . import _lib  # noqa: F401,E402
+from . import dist  # noqa: F401,E402

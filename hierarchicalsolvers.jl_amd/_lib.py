@@ -55,7 +55,7 @@ EXPORTS = [
     "hs_options_default", "hs_factor_d", "hs_factor_z", "hs_ldiv_d", "hs_ldiv_z", "hs_ldiv_dev_d", "hs_ldiv_dev_z",
     "hs_maxrank", "hs_is_complex", "hs_size", "hs_free", "hs_last_error", "hs_last_error_info", "hs_get_stats",
     "hs_node_info", "hs_node_export", "hs_node_export_piv", "hs_device_info",
-    "hs_analyze", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
+    "hs_analyze", "hs_plan", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak",
@@ -99,6 +99,8 @@ def lib():
         f.restype = C.c_int
     L.hs_analyze.argtypes = [C.c_int, i64, p_i64, p_i64, C.POINTER(hs_tree), C.POINTER(hs_options), i64, i64, C.POINTER(vp)]
     L.hs_analyze.restype = C.c_int
+    L.hs_plan.argtypes = [C.c_int, i64, C.POINTER(hs_tree), C.POINTER(hs_options), i64, i64, C.POINTER(vp)]
+    L.hs_plan.restype = C.c_int
     L.hs_numeric_begin.argtypes = [vp, vp, C.c_int]
     L.hs_numeric_begin.restype = C.c_int
     L.hs_numeric_levels.argtypes = [vp, i64, i64]

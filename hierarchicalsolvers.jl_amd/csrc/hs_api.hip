@@ -374,17 +374,17 @@ static void dmalloc(void** p, size_t bytes, const char* what) {
 // ------------------------------------------------------------------------------------------------
 template <class T>
 static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* rowval, const hs_tree* tree, const hs_options* opts_in,
-                               int rank, int nranks) {
+                               int rank, int nranks, bool plan_only = false) {
   hs_options opts;
   if (opts_in)
     opts = *opts_in;
   else
     hs_options_default(&opts);
   chkopts(opts);
-  if (n <= 0 || !colptr || !rowval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: empty matrix");
-  if (colptr[0] != 1) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: colptr must be 1-based (SparseMatrixCSC)");
+  if (n <= 0 || (!plan_only && (!colptr || !rowval))) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: empty matrix");
+  if (!plan_only && colptr[0] != 1) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: colptr must be 1-based (SparseMatrixCSC)");
   if (nranks < 1 || rank < 0 || rank >= nranks) HS_FAIL(HS_ERR_ARGUMENT, rank, "ArgumentError: rank %d of %d", rank, nranks);
-  require_device();
+  if (!plan_only) require_device();
 
   hs_handle* h = new hs_handle();
   try {
@@ -476,6 +476,13 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     h->inv_elems = inv;
     h->sb_elems = sb_total;
     h->int_elems = ints;
+    if (plan_only) {  // host-side plan only (ownership, exchanges, sizes): no device is touched
+      h->stats.n = n;
+      h->stats.nnodes = h->nreal;
+      h->stats.nlevels = nlev;
+      h->stats.bytes_factors = (double)(fac + inv) * sizeof(T);
+      return h;
+    }
 
     HS_HIP(hipStreamCreate(&h->stream));
     HS_HIP(hipEventCreate(&h->ev0));
@@ -636,6 +643,10 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
 // ------------------------------------------------------------------------------------------------
 static void check_handle(const hs_handle* h) {
   if (!h) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: null factorization handle");
+}
+static void check_device_handle(const hs_handle* h) {
+  check_handle(h);
+  if (!h->d_nodes) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: handle holds a host-side plan only (hs_plan); use hs_analyze");
 }
 
 template <class T>
@@ -818,8 +829,18 @@ extern "C" int hs_analyze(int is_complex, int64_t n, const int64_t* colptr, cons
                              : analyze_impl<double>(n, colptr, rowval, tree, opts, (int)rank, (int)nranks));
 }
 
+extern "C" int hs_plan(int is_complex, int64_t n, const hs_tree* tree, const hs_options* opts, int64_t rank, int64_t nranks, hs_handle** out) {
+  if (!out) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: out == NULL");
+    return HS_ERR_ARGUMENT;
+  }
+  *out = nullptr;
+  HS_GUARD(*out = is_complex ? analyze_impl<cplx>(n, nullptr, nullptr, tree, opts, (int)rank, (int)nranks, true)
+                             : analyze_impl<double>(n, nullptr, nullptr, tree, opts, (int)rank, (int)nranks, true));
+}
+
 extern "C" int hs_numeric_begin(hs_handle* h, const void* nzval, int on_device) {
-  HS_GUARD(check_handle(h); if (h->is_complex) numeric_begin<cplx>(h, nzval, on_device); else numeric_begin<double>(h, nzval, on_device));
+  HS_GUARD(check_device_handle(h); if (h->is_complex) numeric_begin<cplx>(h, nzval, on_device); else numeric_begin<double>(h, nzval, on_device));
 }
 extern "C" int hs_numeric_levels(hs_handle* h, int64_t lv_from, int64_t lv_to) {
   HS_GUARD(check_handle(h); if (h->is_complex) numeric_levels<cplx>(h, (int)lv_from, (int)lv_to);

@@ -150,22 +150,24 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
     s_what[t] = c0 + t;
   }
   __syncthreads();
+  __shared__ int s_pl[HS_PB];
+  if (t < HS_PB) s_pl[t] = (t < w) ? nd.pivlist[t] : -1;
+  __syncthreads();
   if (t == 0) {
     // winners (rows by their position at panel start, in elimination order) -> LAPACK-style swaps.
     // A row from below the top block sits where it started until it is picked; rows that started in
     // the top block are tracked through `where`; positions c0+j, j < k, are final.
+    int first_bad = 0;
     for (int k = 0; k < w; ++k) {
-      const int r = nd.pivlist[k];
+      const int r = s_pl[k];
       const int target = c0 + k;
       int p = target;
       if (r < 0) {  // no pivot: leave the row, flag the front singular
-        int old = *nd.info;
-        if (old == 0 || old > c0 + k + 1) *nd.info = c0 + k + 1;
+        if (first_bad == 0) first_bad = c0 + k + 1;
       } else {
         p = (r >= c0 && r < c0 + w) ? s_where[r - c0] : r;
       }
       s_piv[k] = p;
-      nd.ipiv[c0 + k] = p;
       if (p != target) {
         const int q = s_what[k];  // always a row that started inside the top block
         s_what[k] = r;
@@ -174,29 +176,40 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
         s_where[q - c0] = p;
       }
     }
+    if (first_bad) {
+      int old = *nd.info;
+      if (old == 0 || old > first_bad) *nd.info = first_bad;
+    }
   }
   __syncthreads();
-  // swap the panel's own columns (thread j owns column c0+j), sequentially over k
+  if (t < w) nd.ipiv[c0 + t] = s_piv[t];
+  // Apply the w swaps to the panel's own columns (thread j owns column c0+j) and, as one more
+  // "column", to the accumulated row permutation -- as ONE gather/scatter of the <= 2w touched rows
+  // (top position k receives the row s_what[k]; the row that started at top position i goes to
+  // s_where[i]), so all loads are independent instead of 2w dependent global round trips.
   if (t < w) {
     T* col = nd.LF + (size_t)(c0 + t) * nd.ldl;
-    for (int k = 0; k < w; ++k) {
-      int p = s_piv[k];
-      if (p != c0 + k) {
-        T tmp = col[c0 + k];
-        col[c0 + k] = col[p];
-        col[p] = tmp;
+    T topv[HS_PB], pivv[HS_PB];
+#pragma unroll
+    for (int i = 0; i < HS_PB; ++i) {
+      topv[i] = (i < w) ? col[c0 + i] : Scal<T>::zero();
+      pivv[i] = (i < w) ? col[s_what[i]] : Scal<T>::zero();
+    }
+#pragma unroll
+    for (int i = 0; i < HS_PB; ++i) {
+      if (i < w) {
+        col[c0 + i] = pivv[i];
+        const int f = s_where[i];
+        if (f < c0 || f >= c0 + w) col[f] = topv[i];
       }
     }
-  } else if (t == 64) {
-    // the accumulated row permutation is one more "column" that takes the same swaps
-    for (int k = 0; k < w; ++k) {
-      int p = s_piv[k];
-      if (p != c0 + k) {
-        int tmp = nd.rperm[c0 + k];
-        nd.rperm[c0 + k] = nd.rperm[p];
-        nd.rperm[p] = tmp;
-      }
-    }
+  } else if (t >= 64 && t < 64 + w) {
+    const int i = t - 64;
+    const int topv = nd.rperm[c0 + i], pivv = nd.rperm[s_what[i]];
+    __builtin_amdgcn_s_waitcnt(0);  // both loads of every lane are complete before any lane stores (one wave)
+    nd.rperm[c0 + i] = pivv;
+    const int f = s_where[i];
+    if (f < c0 || f >= c0 + w) nd.rperm[f] = topv;
   }
   __syncthreads();
   // load the top w x w block (identity-padded to 32); il = iu = I

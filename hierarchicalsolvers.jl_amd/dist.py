@@ -27,7 +27,7 @@ from . import _lib
 from .nesteddissection import flatten_tree
 from .solver import SolverOptions, chkopts
 
-__all__ = ["Plan", "HipBackend", "run_numeric", "run_solve", "StagedSolver"]
+__all__ = ["Plan", "HipBackend", "run_numeric", "run_solve", "StagedSolver", "plan_only", "TorchComm"]
 
 
 class Plan:
@@ -60,21 +60,26 @@ class _NullComm:
 
 
 class TorchComm:
-    """torch.distributed point-to-point + all-reduce (backend nccl = RCCL on ROCm; gloo on CPU)."""
+    """torch.distributed point-to-point + all-reduce (backend nccl = RCCL on ROCm; gloo on CPU).
+    Complex tensors travel as their real view (same bytes; not every backend takes complex dtypes)."""
 
     def __init__(self):
+        import torch
         import torch.distributed as dist
 
-        self.dist = dist
+        self.dist, self.torch = dist, torch
+
+    def _r(self, t):
+        return self.torch.view_as_real(t) if t.is_complex() else t
 
     def send(self, t, dst):
-        self.dist.send(t, dst=dst)
+        self.dist.send(self._r(t), dst=dst)
 
     def recv(self, t, src):
-        self.dist.recv(t, src=src)
+        self.dist.recv(self._r(t), src=src)
 
     def all_reduce(self, t):
-        self.dist.all_reduce(t)
+        self.dist.all_reduce(self._r(t))
         return t
 
     def barrier(self):
@@ -138,6 +143,27 @@ def run_solve(backend, plan, rank, comm, b):
         backend.comm_sync()
         backend.assign(b, out)
     return b
+
+
+def _tree_struct(nd, nd_loc):
+    flat = flatten_tree(nd, nd_loc)
+    t = _lib.hs_tree()
+    t.nnodes = flat["nnodes"]
+    for k in ("left", "right", "int_ptr", "int_idx", "bnd_ptr", "bnd_idx", "iloc_ptr", "iloc_idx", "bloc_ptr", "bloc_idx"):
+        flat[k] = np.ascontiguousarray(flat[k], dtype=np.int64)
+        setattr(t, k, flat[k].ctypes.data_as(_lib.p_i64))
+    return t, flat
+
+
+def plan_only(A, nd, nd_loc, rank=0, nranks=1, opts=None, **kw):
+    """Host-side plan (``hs_plan``): returns the raw handle (free it with ``hs_free``); no GPU needed."""
+    opts = (opts or SolverOptions(swlevel=0)).copy(**kw)
+    chkopts(opts)
+    t, _keep = _tree_struct(nd, nd_loc)
+    co = opts.to_c()
+    h = C.c_void_p()
+    _lib.check(_lib.lib().hs_plan(int(np.iscomplexobj(A.data)), A.shape[0], C.byref(t), C.byref(co), rank, nranks, C.byref(h)))
+    return h
 
 
 class HipBackend:

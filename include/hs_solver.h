@@ -115,6 +115,9 @@ int hs_ldiv_dev_z(hs_handle* F, double* dC, int64_t ldc, const double* dB, int64
  * hs_exchange_info for WHAT crosses ranks and hs_set_schur_buffer / hs_pack_bnd / hs_unpack_bnd for WHERE. */
 int hs_analyze(int is_complex, int64_t n, const int64_t* colptr, const int64_t* rowval, const hs_tree* tree,
                const hs_options* opts, int64_t rank, int64_t nranks, hs_handle** out);
+/* Host-side plan only (ownership, exchange list, sizes): touches no device, for schedule tests and sizing. */
+int hs_plan(int is_complex, int64_t n, const hs_tree* tree, const hs_options* opts, int64_t rank, int64_t nranks,
+            hs_handle** out);
 int hs_numeric_begin(hs_handle* F, const void* nzval, int nzval_on_device);
 int hs_numeric_levels(hs_handle* F, int64_t level_from, int64_t level_to); /* deepest-first: from >= to; root = 1 */
 int hs_numeric_end(hs_handle* F); /* synchronise; HS_ERR_SINGULAR if a front hit an exactly zero pivot */

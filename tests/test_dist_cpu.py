@@ -1,0 +1,238 @@
+"""N > 1 path on the CPU: the multi-rank schedule of hierarchicalsolvers.jl_amd/dist.py (`run_numeric`,
+`run_solve` -- the SAME code the GPU path runs) driven over torch.distributed/gloo with an
+oracle-backed backend.  It checks that the subtree partition, the Schur-complement exchanges at the
+joins and the boundary-vector exchanges of ldiv! reproduce the serial oracle solution.
+
+The partition itself (who owns which front, what crosses ranks) is checked against an independent
+restatement of the ownership rule.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_plan(hs, nd, nranks):
+    """Independent restatement of the ownership rule: cut at level p+1, 2^p = nranks;
+    a front above the cut belongs to the first rank of its group."""
+    from hierarchicalsolvers_jl_amd.dist import Plan
+
+    nodes = hs.postorder_nodes(nd)
+    ids = {id(x): k for k, x in enumerate(nodes)}
+    owner, level = {}, {}
+
+    def walk(x, lv, lo, cnt):
+        owner[ids[id(x)]] = lo
+        level[ids[id(x)]] = lv
+        if x.left is not None:
+            if cnt > 1:
+                walk(x.left, lv + 1, lo, cnt // 2)
+                walk(x.right, lv + 1, lo + cnt // 2, cnt // 2)
+            else:
+                walk(x.left, lv + 1, lo, 1)
+                walk(x.right, lv + 1, lo, 1)
+
+    walk(nd, 1, 0, nranks)
+    ex = []
+    for k, x in enumerate(nodes):
+        for c in (x.left, x.right):
+            if c is not None and owner[ids[id(c)]] != owner[k]:
+                ex.append(dict(node=ids[id(c)], level=level[ids[id(c)]], src=owner[ids[id(c)]], dst=owner[k], nb=len(c.bnd), nelems=len(c.bnd) ** 2))
+    p = int(np.log2(nranks))
+    return Plan(max(level.values()), p + 1, ex, nranks), owner, level
+
+
+class OracleBackend:
+    """The backend interface of dist.py on top of the NumPy oracle: one front at a time, fronts owned by
+    other ranks are never touched.  Exchange buffers are CPU torch tensors."""
+
+    def __init__(self, A, ond, ond_loc, owner, level, rank):
+        import torch
+
+        from oracle import hs_oracle as O
+
+        self.O, self.torch = O, torch
+        self.A, self.rank = A.tocsc(), rank
+        self.nodes, self.locs = [], []
+
+        def walk(x, xl):
+            if x.left is not None:
+                walk(x.left, xl.left)
+                walk(x.right, xl.right)
+            self.nodes.append(x)
+            self.locs.append(xl)
+
+        walk(ond, ond_loc)
+        self.ids = {id(x): k for k, x in enumerate(self.nodes)}
+        self.owner, self.level = owner, level
+        self.F = {}  # node id -> FactorNode (owned) or a stub holding a received S
+        self.is_c = np.iscomplexobj(A.data)
+        self.dtype = np.complex128 if self.is_c else np.float64
+        self.tdtype = torch.complex128 if self.is_c else torch.float64
+        self._schur = {}
+
+    # -- numeric ------------------------------------------------------------------------------------------
+    def numeric_begin(self):
+        self.F = {}
+
+    def numeric_levels(self, lv_from, lv_to):
+        O = self.O
+        opts = O.SolverOptions(swlevel=0)
+        for lv in range(lv_from, lv_to - 1, -1):
+            for k, x in enumerate(self.nodes):
+                if self.level[k] != lv or self.owner[k] != self.rank:
+                    continue
+                if x.left is None:
+                    self.F[k] = O._factor_leaf(self.A, x, self.locs[k], False, opts)
+                else:
+                    Fl, Fr = self.F[self.ids[id(x.left)]], self.F[self.ids[id(x.right)]]
+                    self.F[k] = O._factor_branch(self.A, Fl, Fr, x, self.locs[k], False, opts)
+
+    def numeric_end(self):
+        pass
+
+    def schur_tensor(self, node):
+        """Owned child: its S (already `S[perm,perm]`, what the parent consumes); remote child: a receive buffer."""
+        nb = len(self.nodes[node].bnd)
+        if node not in self._schur:
+            self._schur[node] = self.torch.zeros(nb * nb, dtype=self.tdtype)
+        t = self._schur[node]
+        if self.owner[node] == self.rank:
+            t.copy_(self.torch.from_numpy(np.ascontiguousarray(self.F[node].S).reshape(-1)))
+        else:  # stub whose .S is a view of the buffer (filled by recv before the parent is factored)
+            stub = type("Stub", (), {})()
+            stub.S = t.numpy().reshape(nb, nb)
+            self.F[node] = stub
+        return t
+
+    def sync(self):
+        pass
+
+    def comm_sync(self):
+        pass
+
+    # -- solve -----------------------------------------------------------------------------------------------
+    def _mine(self, lv_lo, lv_hi):
+        return [k for k in range(len(self.nodes)) if lv_lo <= self.level[k] <= lv_hi and self.owner[k] == self.rank]
+
+    def fwd(self, b, lv_from, lv_to):  # post-order over owned fronts, deepest level first (factornode.jl:77-82)
+        O = self.O
+        for lv in range(lv_from, max(lv_to, 1) - 1, -1):
+            for k in self._mine(lv, lv):
+                F = self.F[k]
+                b[F.bnd - 1] = b[F.bnd - 1] - O._dense(F.L) @ b[F.int - 1]
+
+    def bwd(self, b, lv_from, lv_to):  # _dsolve! + _rsolve! fused per front, root first (factornode.jl:83-99)
+        O = self.O
+        for lv in range(max(lv_from, 1), lv_to + 1):
+            for k in self._mine(lv, lv):
+                F = self.F[k]
+                y = O.blockldiv_inplace(F.D, b[F.int - 1][:, None])[:, 0] if isinstance(F.D, O.BlockFactorization) else O._ldiv(F.D, b[F.int - 1])
+                b[F.int - 1] = y - O._dense(F.R) @ b[F.bnd - 1]
+
+    def pack_bnd(self, node, b):
+        return self.torch.from_numpy(np.ascontiguousarray(b[self.nodes[node].bnd - 1]))
+
+    def bnd_buffer(self, node):
+        return self.torch.zeros(len(self.nodes[node].bnd), dtype=self.tdtype)
+
+    def unpack_bnd(self, node, b, buf):
+        b[self.nodes[node].bnd - 1] = buf.numpy()
+
+    def extract_owned(self, b):
+        out = np.zeros_like(b)
+        for k in self._mine(1, 10**9):
+            out[self.nodes[k].int - 1] = b[self.nodes[k].int - 1]
+        return self.torch.from_numpy(out)
+
+    def assign(self, b, out):
+        b[:] = out.numpy()
+
+
+def _worker(rank, world, port, name, q):
+    try:
+        import torch
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hsamd
+
+        hs = hsamd.load()
+        from helpers import prepare
+        from hierarchicalsolvers_jl_amd.dist import TorchComm, run_numeric, run_solve
+        from oracle import hs_oracle as O
+
+        shape, kind, nmax = name
+        P = prepare(hs, shape, kind=kind, nmax=nmax, rhs="randn")
+        plan, owner, level = build_plan(hs, P["nd"], world)
+        be = OracleBackend(P["A"], P["ond"], P["ond_loc"], owner, level, rank)
+        comm = TorchComm()
+        run_numeric(be, plan, rank, comm)
+        b = np.array(P["b"], dtype=be.dtype)
+        run_solve(be, plan, rank, comm, b)
+        xs = O.ldiv(O.factor(P["A"], P["ond"], P["ond_loc"], swlevel=0), P["b"])  # serial oracle
+        err = float(np.linalg.norm(b - xs) / np.linalg.norm(xs))
+        nsent = sum(1 for e in plan.exchanges if e["src"] == rank)
+        q.put((rank, err, nsent, len(plan.exchanges)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "ERR " + repr(e) + traceback.format_exc(), 0, 0))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("name", [((17, 13), "poisson", 12), ((8, 8, 6), "helmholtz", 30)])
+def test_subtree_partition_over_gloo(world, name):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 7 + world * 13 + len(name[0])) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, nsent, nex in sorted(res):
+        assert not isinstance(err, str), err
+        assert err < 1e-10, (rank, err)
+        assert nex == world - 1  # one Schur complement crosses ranks per join above the cut
+    assert sum(r[2] for r in res) == world - 1
+
+
+def test_plan_matches_library(hs):
+    """The C library's ownership / exchange list (hs_plan, host only -- no GPU) equals the independent restatement."""
+    import ctypes as C
+
+    from helpers import prepare
+
+    P = prepare(hs, (20, 12), kind="poisson", nmax=10)
+    L = hs._lib.lib()
+    for world in (1, 2, 4, 8):
+        plan, owner, level = build_plan(hs, P["nd"], world)
+        h = hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=world)
+        try:
+            assert L.hs_nlevels(h) == plan.nlevels and L.hs_cut_level(h) == plan.cut_level
+            for k, o in owner.items():
+                assert L.hs_node_owner(h, k) == o
+            out6 = (C.c_int64 * 6)()
+            got = []
+            for k in range(L.hs_num_exchanges(h)):
+                hs._lib.check(L.hs_exchange_info(h, k, out6))
+                got.append((out6[0], out6[1], out6[2], out6[3], out6[4]))
+            want = [(e["node"], e["level"], e["src"], e["dst"], e["nb"]) for e in plan.exchanges]
+            assert sorted(got) == sorted(want)
+        finally:
+            L.hs_free(h)
+    with pytest.raises(ValueError, match="power of two"):
+        hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=3)
