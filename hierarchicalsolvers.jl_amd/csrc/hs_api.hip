@@ -19,7 +19,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/hs_solver.h"
@@ -168,8 +170,10 @@ struct hs_handle {
   bool sb_kept = false;
   bool numeric_open = false, factored = false;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // high-priority side stream for look-ahead panels
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Profiler prof;
+  std::vector<std::pair<int, hipEvent_t>> level_events;
   double flops = 0.0;
   hs_stats stats;
 };
@@ -185,6 +189,7 @@ static void free_handle(hs_handle* h) {
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -485,6 +490,11 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     }
 
     HS_HIP(hipStreamCreate(&h->stream));
+    {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+      if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess) h->stream2 = nullptr;
+    }
     HS_HIP(hipEventCreate(&h->ev0));
     HS_HIP(hipEventCreate(&h->ev1));
     dmalloc(&h->d_fac, fac * sizeof(T), "the factors (LF/UR)");
@@ -697,8 +707,14 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     launch_gather<T>(dn, nb_, L.maxm, h->d_colptr, h->d_rowval, (const T*)h->d_nz, h->d_own, h->d_pos, s);
     launch_scatter<T>(dn, dsc_all + L.sc_off, (int)L.sc_cnt, L.maxnbc, s);
     h->prof.end(ea, HS_CAT_ASSEMBLE, s);
-    Sched<T> sch{dn, nb_, L.maxni, L.maxnb, L.maxm, s, &h->prof, L.h_ni.data(), L.h_nb.data()};
+    Sched<T> sch{dn, nb_, L.maxni, L.maxnb, L.maxm, s, &h->prof, L.h_ni.data(), L.h_nb.data(), h->stream2};
     sch.factor_fronts();
+    if (h->opts.profile) {  // per-level wall time (HS_VERBOSE_LEVELS=1 prints it at hs_numeric_end)
+      hipEvent_t e = nullptr;
+      (void)hipEventCreate(&e);
+      (void)hipEventRecord(e, s);
+      h->level_events.push_back({lv, e});
+    }
   }
 }
 
@@ -713,6 +729,26 @@ static void numeric_end(hs_handle* h) {
   h->stats.t_total = ms * 1e-3;
   Profiler& prof = h->prof;
   prof.collect();
+  if (!h->level_events.empty()) {
+    const char* ev = getenv("HS_VERBOSE_LEVELS");
+    hipEvent_t prev = h->ev0;
+    for (auto& le : h->level_events) {
+      float lms = 0.f;
+      (void)hipEventElapsedTime(&lms, prev, le.second);
+      if (ev && ev[0] == '1') {
+        const LevelH& L = h->levels[le.first];
+        double fl = 0.0;
+        for (int id : L.mine) fl += front_flops(h->nodes[id].ni, h->nodes[id].nb);
+        if (h->is_complex) fl *= 4.0;
+        fprintf(stderr, "[hs] level %2d: %4zu fronts, max (ni,nb)=(%d,%d)  %9.3f ms  %8.2f TFLOP/s (minimal count)\n", le.first, L.mine.size(),
+                L.maxni, L.maxnb, lms, lms > 0 ? fl / (lms * 1e-3) / 1e12 : 0.0);
+      }
+      if (prev != h->ev0) (void)hipEventDestroy(prev);
+      prev = le.second;
+    }
+    if (prev != h->ev0) (void)hipEventDestroy(prev);
+    h->level_events.clear();
+  }
   h->stats.t_gemm = prof.ms[HS_CAT_GEMM] * 1e-3;
   h->stats.t_panel = prof.ms[HS_CAT_PANEL] * 1e-3;
   h->stats.t_trsm = (prof.ms[HS_CAT_TRSM] + prof.ms[HS_CAT_LASWP]) * 1e-3;

@@ -62,6 +62,7 @@ struct Sched {
   Profiler* pf;
   const int* h_ni;  // per-front sizes on the host (exact flop accounting); may be null
   const int* h_nb;
+  hipStream_t s2 = nullptr;  // optional high-priority side stream: look-ahead panels for large fronts
 
   // HS_DEBUG_SYNC=1: synchronise after every launch and report the first failing one (diagnostics only)
   void dbg(const char* what, int a = 0, int b = 0, int c = 0, int d = 0) {
@@ -161,8 +162,57 @@ struct Sched {
       laswp(HS_MAT_LF, c0, mid, mid, c1);
     }
   }
+  // Blocked right-looking LU with look-ahead for batches of LARGE fronts (few fronts per level: the
+  // 32-column panel chain -- tournament rounds, pivot, L21, swaps -- would otherwise run alone on the
+  // chip; at Poisson 128^3 the root front spent more time in it than in its GEMMs).  Block column
+  // j+1 is brought up to date first and factored on the side stream while the main stream applies
+  // block j to the rest of the trailing matrix and to Aib.  Left swaps are applied once at the end.
+  static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+  }
+  void factor_fronts_lookahead(int NB) {
+    Sched<T> side = *this;
+    side.s = s2;
+    side.s2 = nullptr;
+    hipEvent_t ev_main, ev_side;
+    (void)hipEventCreateWithFlags(&ev_main, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&ev_side, hipEventDisableTiming);
+    lu_rec(0, NB);
+    for (int c0 = 0; c0 < maxni; c0 += NB) {
+      const int c1 = c0 + NB, c2 = c1 + NB;
+      const bool has_next = c1 < maxni;
+      if (has_next) {
+        laswp(HS_MAT_LF, c1, c2, c0, c1);
+        trsm_rec(HS_MAT_LF, c0, c1, c1, c2);
+        gemm(HS_MAT_LF, HS_MAT_LF, c1, HS_BIG, c1, c2, c0, c1);
+        (void)hipEventRecord(ev_main, s);
+        (void)hipStreamWaitEvent(s2, ev_main, 0);
+        side.lu_rec(c1, c2);
+        (void)hipEventRecord(ev_side, s2);
+        laswp(HS_MAT_LF, c2, HS_BIG, c0, c1);
+        trsm_rec(HS_MAT_LF, c0, c1, c2, HS_BIG);
+        gemm(HS_MAT_LF, HS_MAT_LF, c1, HS_BIG, c2, HS_BIG, c0, c1);
+      }
+      if (maxnb > 0) {
+        laswp(HS_MAT_UR, 0, HS_BIG, c0, c1);
+        trsm_rec(HS_MAT_UR, c0, c1, 0, HS_BIG);
+        gemm(HS_MAT_UR, HS_MAT_UR, c1, HS_BIG, 0, HS_BIG, c0, c1);
+      }
+      if (has_next) (void)hipStreamWaitEvent(s, ev_side, 0);
+    }
+    for (int c0 = 0; c0 + NB < maxni; c0 += NB) laswp(HS_MAT_LF, c0, c0 + NB, c0 + NB, HS_BIG);
+    if (maxnb > 0) gemm(HS_MAT_SB, HS_MAT_UR, 0, HS_BIG, 0, HS_BIG, 0, HS_BIG);
+    (void)hipEventDestroy(ev_main);
+    (void)hipEventDestroy(ev_side);
+  }
   void factor_fronts() {
     if (maxni <= 0) return;
+    static const int la_min = env_int("HS_LA_MIN", 6144), la_nb = env_int("HS_LA_NB", 1024);
+    if (s2 && la_nb >= HS_PB && (la_nb & (la_nb - 1)) == 0 && maxni >= la_min && maxni > la_nb) {
+      factor_fronts_lookahead(la_nb);
+      return;
+    }
     int P2 = HS_PB;
     while (P2 < maxni) P2 *= 2;
     lu_rec(0, P2);
