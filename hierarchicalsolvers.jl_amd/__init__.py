@@ -14,3 +14,4 @@ from .solver import SolverOptions, chkopts, factor, factorize, FactorNode, ldiv,
 from ._lib import DimensionMismatch, SingularException, DeviceError, UnsupportedError  # noqa: F401,E402
 from . import _lib  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
+from .gmres import gmres  # noqa: F401,E402

@@ -84,6 +84,13 @@ def lib():
             f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build() or `make -C {CSRC}`); "
             "there is no CPU fallback"
         )
+    # PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's).  Two HSA
+    # runtimes cannot share a process, so when torch is installed let it load its runtime FIRST; this
+    # library then binds to the already-loaded one.  (A Julia host has no torch and uses /opt/rocm's.)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.hs_options_default.argtypes = [C.POINTER(hs_options)]

@@ -68,18 +68,34 @@ class TorchComm:
         import torch.distributed as dist
 
         self.dist, self.torch = dist, torch
+        # gloo moves host memory: device tensors are staged through the host (rehearsals of the N > 1
+        # path on a single GPU; production uses nccl = RCCL, device to device over xGMI)
+        self.stage = dist.get_backend() == "gloo"
 
     def _r(self, t):
         return self.torch.view_as_real(t) if t.is_complex() else t
 
     def send(self, t, dst):
-        self.dist.send(self._r(t), dst=dst)
+        t = self._r(t)
+        self.dist.send(t.cpu() if (self.stage and t.is_cuda) else t, dst=dst)
 
     def recv(self, t, src):
-        self.dist.recv(self._r(t), src=src)
+        r = self._r(t)
+        if self.stage and r.is_cuda:
+            h = self.torch.empty(r.shape, dtype=r.dtype)
+            self.dist.recv(h, src=src)
+            r.copy_(h)
+        else:
+            self.dist.recv(r, src=src)
 
     def all_reduce(self, t):
-        self.dist.all_reduce(self._r(t))
+        r = self._r(t)
+        if self.stage and r.is_cuda:
+            h = r.cpu()
+            self.dist.all_reduce(h)
+            r.copy_(h)
+        else:
+            self.dist.all_reduce(r)
         return t
 
     def barrier(self):
