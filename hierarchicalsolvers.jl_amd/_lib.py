@@ -58,7 +58,7 @@ EXPORTS = [
     "hs_analyze", "hs_plan", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned",
-    "hsk_gemm_d", "hsk_gemm_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak",
+    "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak",
 ]
 
 _lib = None
@@ -159,6 +159,9 @@ def lib():
         f.restype = C.c_int
     for f in (L.hsk_front_factor_d, L.hsk_front_factor_z):
         f.argtypes = [i64, i64, i64, p_f64, p_f64, p_f64, p_f64, p_i64, p_i64, p_f64]
+        f.restype = C.c_int
+    for f in (L.hsk_lowrank_d, L.hsk_lowrank_z):
+        f.argtypes = [i64, i64, p_f64, C.c_double, C.c_double, i64, i64, p_i64, p_f64, p_f64, i64]
         f.restype = C.c_int
     L.hsk_mfma_f64_peak.argtypes = [C.c_int, C.c_int]
     L.hsk_mfma_f64_peak.restype = C.c_double

@@ -80,6 +80,7 @@ struct NodeDesc {
   int ni, nb, m;
   int ldl, ldu, lds;
   int ni1, nb1;  // branch: sizes of the left child's contribution to int / bnd (front split points); leaf: ni, nb
+  int pivrows;   // pivot candidates are rows [c0, pivrows): ni for a front (`\\` on Aii pivots inside Aii only), all rows for a sketch
   int isleaf;
   int node;      // post-order id
   // the same three matrices indexed by HS_MAT_*: kernels that pick a matrix at run time index these
@@ -88,6 +89,7 @@ struct NodeDesc {
   T* mp[3];
   int mld[3], mrows[3], mcols[3];
   __host__ void finalize() {
+    if (pivrows <= 0) pivrows = ni;
     mp[0] = LF; mp[1] = UR; mp[2] = SB;
     mld[0] = ldl; mld[1] = ldu; mld[2] = lds;
     mrows[0] = m; mrows[1] = ni; mrows[2] = nb;

@@ -63,6 +63,7 @@ struct Sched {
   const int* h_ni;  // per-front sizes on the host (exact flop accounting); may be null
   const int* h_nb;
   hipStream_t s2 = nullptr;  // optional high-priority side stream: look-ahead panels for large fronts
+  int maxpiv = 0;            // largest pivot-candidate row limit in the batch (0: = maxni)
 
   // HS_DEBUG_SYNC=1: synchronise after every launch and report the first failing one (diagnostics only)
   void dbg(const char* what, int a = 0, int b = 0, int c = 0, int d = 0) {
@@ -102,7 +103,7 @@ struct Sched {
   void panel(int pb) {
     int c0 = pb * HS_PB;
     if (c0 >= maxni) return;
-    int cnt = maxni - c0, nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
+    int cnt = (maxpiv > 0 ? maxpiv : maxni) - c0, nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
     hipEvent_t e0 = pf->begin(s);
     for (int round = 0;; ++round) {
       launch_tournament_round<T>(dn, nbatch, pb, round, nch, s);

@@ -6,6 +6,7 @@
 
 #include "../../include/hs_kernels.h"
 #include "hs_sched.h"
+#include "hs_lowrank.h"
 
 #define CK(call)                                                                                   \
   do {                                                                                             \
@@ -159,4 +160,49 @@ extern "C" int hsk_front_factor_d(int64_t count, int64_t ni, int64_t nb, const d
 extern "C" int hsk_front_factor_z(int64_t count, int64_t ni, int64_t nb, const double* F, double* outLF, double* outUR, double* outSB,
                                   int64_t* out_rperm, int64_t* info, double* ms_out) {
   return front_hook<cplx>(count, ni, nb, (const cplx*)F, (cplx*)outLF, (cplx*)outUR, (cplx*)outSB, out_rperm, info, ms_out);
+}
+
+// Low-rank compression of a dense rows x cols block (column-major host array): returns the rank r and
+// the dense factors C (rows x r) and Z (r x cols), X ~= C * Z, built from the device representation.
+template <class T>
+static int lowrank_hook(int64_t rows, int64_t cols, const T* X, double atol, double rtol, int64_t kinit, int64_t seed, int64_t* r_out, T* Cout,
+                        T* Zout, int64_t cap) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+    hs_set_error(HS_ERR_DEVICE, 0, "no HIP device available");
+    return HS_ERR_DEVICE;
+  }
+  T* dX = nullptr;
+  const int ldx = ((int)rows + 1) / 2 * 2;
+  CK(hipMalloc((void**)&dX, sizeof(T) * ((size_t)ldx * cols + 32)));
+  CK(hipMemcpy2D(dX, sizeof(T) * ldx, X, sizeof(T) * rows, sizeof(T) * rows, cols, hipMemcpyHostToDevice));
+  LowRank<T> lr;
+  int st = lowrank_compress<T>(dX, ldx, (int)rows, (int)cols, atol, rtol, (int)kinit, (uint64_t)seed, 0, &lr);
+  if (st != 0) return st;
+  *r_out = lr.r;
+  if (lr.r > cap) {
+    hs_set_error(HS_ERR_ARGUMENT, lr.r, "rank %d exceeds the output capacity %lld", lr.r, (long long)cap);
+    return HS_ERR_ARGUMENT;
+  }
+  std::vector<T> hL((size_t)lr.ldp * lr.k);
+  std::vector<int> rp(rows);
+  CK(hipMemcpy(hL.data(), lr.Lp, sizeof(T) * hL.size(), hipMemcpyDeviceToHost));
+  CK(hipMemcpy(rp.data(), lr.rperm, sizeof(int) * rows, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < lr.r; ++j) {
+      T v = (i == j) ? Scal<T>::one() : (i > j ? hL[(size_t)i + (size_t)j * lr.ldp] : Scal<T>::zero());
+      Cout[(size_t)rp[i] + (size_t)j * rows] = v;
+    }
+  if (lr.r > 0) CK(hipMemcpy2D(Zout, sizeof(T) * lr.r, lr.Z, sizeof(T) * lr.ldz, sizeof(T) * lr.r, cols, hipMemcpyDeviceToHost));
+  lowrank_free(lr);
+  (void)hipFree(dX);
+  return HS_OK;
+}
+extern "C" int hsk_lowrank_d(int64_t rows, int64_t cols, const double* X, double atol, double rtol, int64_t kinit, int64_t seed, int64_t* r_out,
+                             double* Cout, double* Zout, int64_t cap) {
+  return lowrank_hook<double>(rows, cols, X, atol, rtol, kinit, seed, r_out, Cout, Zout, cap);
+}
+extern "C" int hsk_lowrank_z(int64_t rows, int64_t cols, const double* X, double atol, double rtol, int64_t kinit, int64_t seed, int64_t* r_out,
+                             double* Cout, double* Zout, int64_t cap) {
+  return lowrank_hook<cplx>(rows, cols, (const cplx*)X, atol, rtol, kinit, seed, r_out, (cplx*)Cout, (cplx*)Zout, cap);
 }

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void init_fronts_kernel(const NodeDesc<T>* __r
   const NodeDesc<T> nd = nodes[blockIdx.y];
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) *nd.info = 0;
-  if (i < nd.ni) nd.rperm[i] = i;
+  if (i < nd.pivrows) nd.rperm[i] = i;
 }
 
 template <class T>

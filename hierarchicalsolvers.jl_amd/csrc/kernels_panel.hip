@@ -60,8 +60,8 @@ __global__ __launch_bounds__(HS_CHUNK) void tournament_kernel(const NodeDesc<T>*
   const int c0 = pb * HS_PB;
   if (c0 >= nd.ni) return;
   const int w = min(HS_PB, nd.ni - c0);
-  // candidate counts per round: cnt_0 = ni - c0, cnt_{r+1} = ceil(cnt_r / 256) * 32
-  int cnt = nd.ni - c0;
+  // candidate counts per round: cnt_0 = pivrows - c0, cnt_{r+1} = ceil(cnt_r / 256) * 32
+  int cnt = nd.pivrows - c0;
   int nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
   for (int r = 0; r < round; ++r) {
     if (nch == 1) return;  // this front finished in an earlier round

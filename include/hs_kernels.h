@@ -31,6 +31,15 @@ int hsk_front_factor_d(int64_t count, int64_t ni, int64_t nb, const double* F, d
 int hsk_front_factor_z(int64_t count, int64_t ni, int64_t nb, const double* F, double* outLF, double* outUR,
                        double* outSB, int64_t* out_rperm, int64_t* info, double* ms_out);
 
+/* Low-rank compression X (rows x cols) ~= C (rows x r) * Z (r x cols) to tolerance max(atol, rtol*|u_11|): the
+ * device primitive behind the compressed Gauss transforms (`_lgauss_transform` / `_rgauss_transform`,
+ * src/factorization.jl:171-182, which call LowRankApprox.pqrfact).  cap = capacity (in columns of C / rows of Z)
+ * of the output arrays; kinit = initial sketch width. */
+int hsk_lowrank_d(int64_t rows, int64_t cols, const double* X, double atol, double rtol, int64_t kinit, int64_t seed,
+                  int64_t* r_out, double* Cout, double* Zout, int64_t cap);
+int hsk_lowrank_z(int64_t rows, int64_t cols, const double* X, double atol, double rtol, int64_t kinit, int64_t seed,
+                  int64_t* r_out, double* Cout, double* Zout, int64_t cap);
+
 /* Measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on every CU (roofline denominator). */
 double hsk_mfma_f64_peak(int waves_per_simd, int iters);
 

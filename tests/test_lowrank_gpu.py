@@ -1,0 +1,73 @@
+"""Low-rank compression primitive (randomized row interpolative decomposition through the front kernels)
+against NumPy: ||X - C Z|| within the requested tolerance, rank close to the numerical rank (SVD)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def compress(hs, X, atol, rtol, kinit=64, seed=1):
+    rows, cols = X.shape
+    cplx = np.iscomplexobj(X)
+    Xf = np.asfortranarray(X)
+    cap = min(rows, cols)
+    Cm = np.zeros((rows, cap), dtype=X.dtype, order="F")
+    Z = np.zeros((cap, cols), dtype=X.dtype)
+    # outputs are written with tight leading dimensions (rows for C, r for Z): use flat buffers
+    Cbuf = np.zeros(rows * cap, dtype=X.dtype)
+    Zbuf = np.zeros(cap * cols, dtype=X.dtype)
+    r = C.c_int64(0)
+    L = hs._lib.lib()
+    fn = L.hsk_lowrank_z if cplx else L.hsk_lowrank_d
+    hs._lib.check(fn(rows, cols, _ptr(Xf), atol, rtol, kinit, seed, C.byref(r), _ptr(Cbuf), _ptr(Zbuf), cap))
+    r = r.value
+    Cm = Cbuf[: rows * r].reshape((rows, r), order="F")
+    Z = Zbuf[: r * cols].reshape((r, cols), order="F")
+    return r, Cm, Z
+
+
+def kernel_matrix(rows, cols, cplx, seed=0, sep=1.5):
+    """Smooth interaction between two separated point clouds: numerically low rank (like a far-field front block)."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((rows, 3))
+    y = rng.random((cols, 3)) + np.array([sep, 0.0, 0.0])
+    d = np.linalg.norm(x[:, None, :] - y[None, :, :], axis=2)
+    K = 1.0 / d
+    if cplx:
+        K = K * np.exp(1j * 3.0 * d)
+    return K
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("rows,cols", [(300, 200), (1000, 777), (257, 1500)])
+@pytest.mark.parametrize("rtol", [1e-2, 1e-6])
+def test_lowrank_kernel_matrix(hs, rows, cols, cplx, rtol):
+    X = kernel_matrix(rows, cols, cplx, seed=rows + cols)
+    r, Cm, Z = compress(hs, X, 0.0, rtol)
+    s = np.linalg.svd(X, compute_uv=False)
+    r_svd = int(np.sum(s > rtol * s[0]))
+    err = np.linalg.norm(X - Cm @ Z, 2) / s[0]
+    assert err < 50 * rtol, (r, r_svd, err)
+    assert r_svd <= r <= 3 * r_svd + 16, (r, r_svd)
+    assert np.max(np.abs(Cm)) < 8.0  # interpolation factor: tournament pivoting keeps |L| modest (not <= 1 like full partial pivoting)
+
+
+def test_lowrank_exact_rank_and_full_rank(hs):
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((400, 37)) @ rng.standard_normal((37, 300))
+    r, Cm, Z = compress(hs, A, 0.0, 1e-10)
+    assert 37 <= r <= 37 + 8
+    assert np.linalg.norm(A - Cm @ Z) / np.linalg.norm(A) < 1e-8
+    B = rng.standard_normal((150, 120))  # full rank: the sketch must grow to min(rows, cols)
+    r, Cm, Z = compress(hs, B, 0.0, 1e-12, kinit=32)
+    assert r == 120
+    assert np.linalg.norm(B - Cm @ Z) / np.linalg.norm(B) < 1e-9
+    Zr = np.zeros((60, 50))
+    r, Cm, Z = compress(hs, Zr, 1e-8, 1e-8)
+    assert r == 0
