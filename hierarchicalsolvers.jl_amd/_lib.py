@@ -54,7 +54,7 @@ HS_BLK_LU, HS_BLK_LBI, HS_BLK_UIB, HS_BLK_S = 0, 1, 2, 3
 EXPORTS = [
     "hs_options_default", "hs_factor_d", "hs_factor_z", "hs_ldiv_d", "hs_ldiv_z", "hs_ldiv_dev_d", "hs_ldiv_dev_z",
     "hs_maxrank", "hs_is_complex", "hs_size", "hs_free", "hs_last_error", "hs_last_error_info", "hs_get_stats",
-    "hs_node_info", "hs_node_export", "hs_node_export_piv", "hs_device_info",
+    "hs_node_info", "hs_node_ranks", "hs_node_export", "hs_node_export_piv", "hs_device_info",
     "hs_analyze", "hs_plan", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned",
@@ -148,6 +148,8 @@ def lib():
     L.hs_get_stats.restype = C.c_int
     L.hs_node_info.argtypes = [vp, i64, p_i64, p_i64, p_i64]
     L.hs_node_info.restype = C.c_int
+    L.hs_node_ranks.argtypes = [vp, i64, p_i64, p_i64]
+    L.hs_node_ranks.restype = C.c_int
     L.hs_node_export.argtypes = [vp, i64, C.c_int, p_f64]
     L.hs_node_export.restype = C.c_int
     L.hs_node_export_piv.argtypes = [vp, i64, p_i64]

@@ -116,6 +116,9 @@ struct NodeH {
   int batch_pos = -1;      // index inside its level's batch of owned fronts
   void* ext_sb = nullptr;  // caller-provided device buffer for the Schur complement (exchange between ranks)
   long long woff = 0;
+  bool compressed = false;  // level <= swlevel && |bnd| >= swsize (factorization.jl:15): low-rank Gauss transforms
+  void* lrL = nullptr;      // LowRank<T>* of Lbi = Abi*U^-1  (nb x ni)
+  void* lrR = nullptr;      // LowRank<T>* of Uib = L^-1*P*Aib (ni x nb)
 };
 
 struct LevelH {
@@ -173,6 +176,10 @@ struct hs_handle {
   hipStream_t stream2 = nullptr;  // high-priority side stream for look-ahead panels
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Profiler prof;
+  void* d_lr_t = nullptr;     // low-rank apply workspace
+  void* d_lr_part = nullptr;
+  size_t lr_t_elems = 0, lr_part_elems = 0;
+  int64_t maxrank = 0;
   std::vector<std::pair<int, hipEvent_t>> level_events;
   double flops = 0.0;
   hs_stats stats;
@@ -181,8 +188,10 @@ struct hs_handle {
 static inline int rup(int x, int a) { return (x + a - 1) / a * a; }
 static inline size_t rups(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+static void free_lowrank_any(hs_handle* h);
 static void free_handle(hs_handle* h) {
   if (!h) return;
+  free_lowrank_any(h);
   void* ptrs[] = {h->d_fac,   h->d_inv, h->d_sb,    h->d_int, h->d_tmpi, h->d_colptr, h->d_rowval, h->d_nz,
                   h->d_nodes, h->d_sc,  h->d_solve, h->d_w1,  h->d_w2,   h->d_part,   h->d_b};
   for (void* p : ptrs)
@@ -363,6 +372,9 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
   }
 }
 
+static void dmalloc(void** p, size_t bytes, const char* what);
+#include "hs_compress.h"
+
 static double front_flops(double ni, double nb) { return (2.0 / 3.0) * ni * ni * ni + 2.0 * ni * ni * nb + 2.0 * ni * nb * nb; }
 
 static void dmalloc(void** p, size_t bytes, const char* what) {
@@ -404,14 +416,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     const int nlev = (int)h->levels.size() - 1;
     // depth(nd) in the reference counts levels; negative swlevel counts from the leaves (factorization.jl:8)
     int64_t swlevel = opts.swlevel < 0 ? std::max<int64_t>(nlev + opts.swlevel, 0) : opts.swlevel;
-    for (int i = 0; i < h->nreal; ++i) {
-      bool compress = (N[i].level <= swlevel) && (N[i].nb >= opts.swsize);  // factorization.jl:15
-      if (compress)
-        HS_FAIL(HS_ERR_UNSUPPORTED, i,
-                "compressed (HSS) elimination requested for node %d (level %d <= swlevel %lld, |bnd| %d >= swsize %lld): "
-                "not built yet in this round; call with swlevel=0 for the exact path",
-                i, N[i].level, (long long)swlevel, N[i].nb, (long long)opts.swsize);
-    }
+    for (int i = 0; i < h->nreal; ++i)  // compression_flag of factorization.jl:15 (phase 1: low-rank Gauss transforms, hs_compress.h)
+      N[i].compressed = (N[i].level <= swlevel) && (N[i].nb >= opts.swsize) && N[i].nb > 0 && N[i].ni > 0 && !N[i].leaf;  // a compressed LEAF keeps dense L, R (factorization.jl:45-59)
 
     // ---- HBM layout (owned fronts: LF/UR/inv; owned + ghost fronts: SB) ------------------------------
     size_t fac = 0, inv = 0, ints = h->fidx_host.size(), tmpi = 0;
@@ -594,6 +600,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           q.LF = d.LF; q.UR = d.UR; q.invL = d.invL; q.invU = d.invU;
           q.rperm = d.rperm; q.fidx = d.fidx;
           q.ni = x.ni; q.nb = x.nb; q.m = x.m; q.ldl = x.ldl; q.ldu = x.ldu;
+          q.compressed = x.compressed ? 1 : 0;
+          q.mrows = x.compressed ? x.ni : x.m;
           q.woff = x.woff;
           q.poff = poff;
           poff += (long long)((x.nb + 511) / 512) * x.ni;
@@ -663,6 +671,7 @@ template <class T>
 static void numeric_begin(hs_handle* h, const void* nzval, int on_device) {
   if (!nzval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: nzval == NULL");
   hipStream_t s = h->stream;
+  free_lowrank_nodes<T>(h);
   HS_HIP(hipMemcpyAsync(h->d_nz, nzval, h->nnz * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   HS_HIP(hipMemsetAsync(h->d_own, 0xff, h->n * sizeof(int), s));
   h->prof = Profiler();
@@ -709,6 +718,7 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     h->prof.end(ea, HS_CAT_ASSEMBLE, s);
     Sched<T> sch{dn, nb_, L.maxni, L.maxnb, L.maxm, s, &h->prof, L.h_ni.data(), L.h_nb.data(), h->stream2};
     sch.factor_fronts();
+    compress_level<T>(h, lv);
     if (h->opts.profile) {  // per-level wall time (HS_VERBOSE_LEVELS=1 prints it at hs_numeric_end)
       hipEvent_t e = nullptr;
       (void)hipEventCreate(&e);
@@ -783,6 +793,7 @@ static void solve_fwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
     launch_fwd_gather<T>(dn, nb_, L.maxni, db, w1, s);
     const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
     for (int blk = 0; blk < nblk; ++blk) launch_fwd_step<T>(dn, nb_, blk, L.maxm, w1, w2, db, s);
+    solve_lr_fwd<T>(h, lv, db, s);
   }
 }
 template <class T>
@@ -800,6 +811,7 @@ static void solve_bwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
     const SolveNode<T>* dn = sn + L.desc_off;
     const int nb_ = (int)L.mine.size();
     launch_int_update<T>(dn, nb_, L.maxni, L.maxnb, db, part, w2, w1, s);
+    solve_lr_bwd<T>(h, lv, db, s);
     const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
     for (int blk = nblk - 1; blk >= 0; --blk) launch_bwd_step<T>(dn, nb_, blk, w1, w2, s);
     launch_bwd_scatter<T>(dn, nb_, L.maxni, db, w2, s);
@@ -1023,8 +1035,27 @@ extern "C" int hs_extract_owned(const hs_handle* h, const void* d_b, void* d_out
 // introspection
 // ------------------------------------------------------------------------------------------------
 extern "C" int64_t hs_maxrank(const hs_handle* F) {
-  (void)F;
-  return 0;  // dense path: S, L, R are dense => every rank term of factornode.jl:49-57 is 0
+  return F ? F->maxrank : 0;  // max over fronts of rank(L), rank(R) (factornode.jl:49-57); 0 on the dense path
+}
+extern "C" int hs_node_ranks(const hs_handle* F, int64_t node, int64_t* rank_L, int64_t* rank_R) {
+  if (!F || node < 0 || node >= F->nnodes) {
+    hs_set_error(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+    return HS_ERR_ARGUMENT;
+  }
+  const NodeH& x = F->nodes[node];
+  int64_t rl = 0, rr = 0;  // 0 = dense Gauss transform, like rank terms of maxrank (factornode.jl:54-55)
+  if (x.compressed && x.lrL && x.lrR) {
+    if (F->is_complex) {
+      rl = ((const LowRank<cplx>*)x.lrL)->r;
+      rr = ((const LowRank<cplx>*)x.lrR)->r;
+    } else {
+      rl = ((const LowRank<double>*)x.lrL)->r;
+      rr = ((const LowRank<double>*)x.lrR)->r;
+    }
+  }
+  if (rank_L) *rank_L = rl;
+  if (rank_R) *rank_R = rr;
+  return x.compressed ? 1 : 0;
 }
 extern "C" int hs_is_complex(const hs_handle* F) { return F && F->is_complex ? 1 : 0; }
 extern "C" int64_t hs_size(const hs_handle* F) { return F ? F->n : 0; }
@@ -1053,6 +1084,12 @@ extern "C" int hs_node_info(const hs_handle* F, int64_t node, int64_t* ni, int64
 template <class T>
 static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) {
   if (!x.mine) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: node is owned by rank %d", x.owner);
+  if (x.compressed && (which == HS_BLK_LBI || which == HS_BLK_UIB)) {  // dense reconstruction C*Z of the low-rank transform
+    const void* lr = which == HS_BLK_LBI ? x.lrL : x.lrR;
+    if (!lr) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: node has no compressed Gauss transforms yet");
+    lowrank_to_dense<T>(*(const LowRank<T>*)lr, out);
+    return;
+  }
   const T* base;
   int rows, cols, ld;
   switch (which) {

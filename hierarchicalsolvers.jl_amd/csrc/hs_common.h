@@ -171,6 +171,8 @@ struct SolveNode {
   const int* rperm;  // ni: (P x)[i] = x[rperm[i]]
   const int* fidx;   // m global ids (0-based), front order [int; bnd]
   int ni, nb, m, ldl, ldu;
+  int mrows;         // rows the dense forward sweep covers: m, or ni when the Gauss transforms are low-rank
+  int compressed;    // 1: L (Abi*Aii^-1) and R (Aii^-1*Aib) are applied through their low-rank factors
   long long woff;    // offset of this node's ni-segment in the work vectors
   long long poff;    // offset of this node's partial-sum scratch (ceil(nb/512) * ni entries)
 };
@@ -185,6 +187,13 @@ void launch_bwd_step(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hi
 template <class T>
 void launch_bwd_scatter(const SolveNode<T>* dn, int nbatch, int maxni, T* b, const T* x, hipStream_t s);
 
+// low-rank Gauss transform  X ~= P' * trap(Lp[:, :r]) * Z  applied to a vector (one front per call):
+//   t = Z * x  (x contiguous, or gathered through xidx when xidx != nullptr)      -> launch_lr_zmul
+//   u = trap(Lp) * t ;  dst[didx ? didx[rp[i]] : rp[i]] -= u[i]                    -> launch_lr_trap
+template <class T>
+void launch_lr_zmul(const T* Z, int ldz, int r, int cols, const T* x, const int* xidx, T* part, T* t, hipStream_t s);
+template <class T>
+void launch_lr_trap(const T* Lp, int ldp, int rows, int r, const int* rp, const T* t, T* dst, const int* didx, hipStream_t s);
 void launch_pack_idx(const int* idx, int cnt, const void* b, void* buf, int esz, hipStream_t s);    // buf[i] = b[idx[i]]
 void launch_unpack_idx(const int* idx, int cnt, void* b, const void* buf, int esz, hipStream_t s);  // b[idx[i]] = buf[i]
 

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const SolveNode<T>* __res
   if (c0 >= nd.ni) return;
   const int wl = min(HS_PB, nd.ni - c0);
   const int r0 = c0 + wl;
-  if (blockIdx.x > 0 && (int)blockIdx.x * 256 >= nd.m - r0) return;
+  if (blockIdx.x > 0 && (int)blockIdx.x * 256 >= nd.mrows - r0) return;
   __shared__ T s_raw[HS_PB];
   __shared__ T s_y[HS_PB];
   const int t = threadIdx.x;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const SolveNode<T>* __res
   }
   __syncthreads();
   const int r = r0 + blockIdx.x * 256 + t;
-  if (r >= nd.m) return;
+  if (r >= nd.mrows) return;
   const T* a = nd.LF + (size_t)r + (size_t)c0 * nd.ldl;
   T acc = Scal<T>::zero();
 #pragma unroll 8
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void int_update_partial_kernel(const SolveNode
                                                                  T* __restrict__ part) {
   const SolveNode<T> nd = nodes[blockIdx.z];
   const int j0 = blockIdx.y * UPD_CS;
-  if (j0 >= nd.nb) return;
+  if (j0 >= nd.nb || nd.compressed) return;
   if ((int)blockIdx.x * 256 >= nd.ni) return;
   const int j1 = min(nd.nb, j0 + UPD_CS);
   __shared__ T s_b[UPD_CS];
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void int_update_reduce_kernel(const SolveNode<
   const SolveNode<T> nd = nodes[blockIdx.y];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nd.ni) return;
-  const int ns = (nd.nb + UPD_CS - 1) / UPD_CS;
+  const int ns = nd.compressed ? 0 : (nd.nb + UPD_CS - 1) / UPD_CS;  // compressed: R is applied by the lr kernels
   T acc = y[nd.woff + i];
   for (int s = 0; s < ns; ++s) acc = acc - part[nd.poff + (long long)s * nd.ni + i];
   w[nd.woff + i] = acc;
@@ -131,6 +131,77 @@ __global__ __launch_bounds__(256) void bwd_scatter_kernel(const SolveNode<T>* __
   if (i >= nd.ni) return;
   b[nd.fidx[i]] = x[nd.woff + i];
 }
+
+// ---- low-rank Gauss transforms (compressed fronts) ---------------------------------------------------
+#define LR_CS 512
+template <class T>
+__global__ __launch_bounds__(256) void lr_zmul_partial_kernel(const T* __restrict__ Z, int ldz, int r, int cols, const T* __restrict__ x,
+                                                              const int* __restrict__ xidx, T* __restrict__ part) {
+  const int j0 = blockIdx.y * LR_CS, j1 = min(cols, j0 + LR_CS);
+  __shared__ T s_x[LR_CS];
+  for (int j = threadIdx.x; j < j1 - j0; j += 256) s_x[j] = xidx ? x[xidx[j0 + j]] : x[j0 + j];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= r) return;
+  const T* z = Z + (size_t)i + (size_t)j0 * ldz;
+  T acc = Scal<T>::zero();
+#pragma unroll 8
+  for (int j = 0; j < j1 - j0; ++j) acc = Scal<T>::fma(z[(size_t)j * ldz], s_x[j], acc);
+  part[(size_t)blockIdx.y * r + i] = acc;
+}
+template <class T>
+__global__ __launch_bounds__(256) void lr_zmul_reduce_kernel(const T* __restrict__ part, int r, int ns, T* __restrict__ t) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= r) return;
+  T acc = Scal<T>::zero();
+  for (int s = 0; s < ns; ++s) acc = acc + part[(size_t)s * r + i];
+  t[i] = acc;
+}
+// u = unit-lower-trapezoid(Lp[:, :r]) * t, one thread per row; dst[(didx ? didx[rp[i]] : rp[i])] -= u[i]
+template <class T>
+__global__ __launch_bounds__(256) void lr_trap_kernel(const T* __restrict__ Lp, int ldp, int rows, int r, const int* __restrict__ rp,
+                                                      const T* __restrict__ t, T* __restrict__ dst, const int* __restrict__ didx) {
+  __shared__ T s_t[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  T acc = Scal<T>::zero();
+  for (int j0 = 0; j0 < r; j0 += 256) {
+    __syncthreads();
+    if (j0 + (int)threadIdx.x < r) s_t[threadIdx.x] = t[j0 + threadIdx.x];
+    __syncthreads();
+    if (i < rows) {
+      const int jn = min(256, r - j0);
+      const T* a = Lp + (size_t)i + (size_t)j0 * ldp;
+      for (int j = 0; j < jn; ++j) {
+        const int col = j0 + j;
+        if (col < i)
+          acc = Scal<T>::fma(a[(size_t)j * ldp], s_t[j], acc);
+        else if (col == i)
+          acc = acc + s_t[j];  // unit diagonal
+      }
+    }
+  }
+  if (i < rows) {
+    const int o = rp[i];
+    const int g = didx ? didx[o] : o;
+    dst[g] = dst[g] - acc;
+  }
+}
+template <class T>
+void launch_lr_zmul(const T* Z, int ldz, int r, int cols, const T* x, const int* xidx, T* part, T* t, hipStream_t s) {
+  if (r <= 0) return;
+  const int ns = (cols + LR_CS - 1) / LR_CS;
+  hipLaunchKernelGGL(lr_zmul_partial_kernel<T>, dim3((r + 255) / 256, ns), dim3(256), 0, s, Z, ldz, r, cols, x, xidx, part);
+  hipLaunchKernelGGL(lr_zmul_reduce_kernel<T>, dim3((r + 255) / 256), dim3(256), 0, s, (const T*)part, r, ns, t);
+}
+template <class T>
+void launch_lr_trap(const T* Lp, int ldp, int rows, int r, const int* rp, const T* t, T* dst, const int* didx, hipStream_t s) {
+  if (r <= 0 || rows <= 0) return;
+  hipLaunchKernelGGL(lr_trap_kernel<T>, dim3((rows + 255) / 256), dim3(256), 0, s, Lp, ldp, rows, r, rp, t, dst, didx);
+}
+template void launch_lr_zmul<double>(const double*, int, int, int, const double*, const int*, double*, double*, hipStream_t);
+template void launch_lr_zmul<cplx>(const cplx*, int, int, int, const cplx*, const int*, cplx*, cplx*, hipStream_t);
+template void launch_lr_trap<double>(const double*, int, int, int, const int*, const double*, double*, const int*, hipStream_t);
+template void launch_lr_trap<cplx>(const cplx*, int, int, int, const int*, const cplx*, cplx*, const int*, hipStream_t);
 
 // ---- multi-rank helpers: boundary segments cross ranks as contiguous vectors ------------------------
 __global__ __launch_bounds__(256) void pack_idx_kernel(const int* __restrict__ idx, int cnt, const char* __restrict__ b, char* __restrict__ buf, int esz) {

@@ -140,6 +140,14 @@ class FactorNode:
         _lib.check(_lib.lib().hs_node_info(self._h, node, C.byref(ni), C.byref(nb), C.byref(lv)))
         return ni.value, nb.value, lv.value
 
+    def node_ranks(self, node):
+        """``(compressed, rank(L), rank(R))`` of one front (ranks are 0 for dense Gauss transforms)."""
+        rl, rr = _lib.i64(), _lib.i64()
+        st = _lib.lib().hs_node_ranks(self._h, node, C.byref(rl), C.byref(rr))
+        if st < 0:
+            _lib.check(st)
+        return bool(st), rl.value, rr.value
+
     def node_blocks(self, node, with_schur=False):
         """Stored blocks of one node: ``LU`` (ni x ni packed), ``Lbi`` (nb x ni), ``Uib`` (ni x nb),
         ``rperm`` (0-based, ``(P x)[i] = x[rperm[i]]``) and optionally ``S`` (needs ``keep_schur``)."""

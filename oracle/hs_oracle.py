@@ -386,7 +386,7 @@ class FactorNode:  # factornode.jl:7-39
 
 
 def _dense(M):
-    return M.dense() if isinstance(M, BlockMatrix) else M
+    return M.dense() if hasattr(M, "dense") else M
 
 
 def maxrank(F):  # factornode.jl:49-57 -- dense path: every rank is 0

@@ -1,0 +1,109 @@
+"""Compressed fronts, phase 1 (low-rank Gauss transforms; D and S dense) on the GPU.
+
+Reference scenario: `factor(A, nd, nd_loc; swlevel=-4, swsize=8, atol=rtol=1e-6, ...)` used as right
+preconditioner of GMRES (test/rungmres.jl:23-48).  Parity unpinned (LowRankApprox / HssMatrices are not in
+the reference tree): the product is compared with `oracle/hs_oracle_lr.py` through quantities both must
+agree on to O(tol) -- solution error, GMRES iteration count -- and with its own dense Gauss transforms.
+"""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from helpers import prepare, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hs():
+    import hsamd
+
+    return hsamd.load()
+
+
+CASES = [
+    (("poisson2d_p1_h64_nmax100", {}), -2, 8),
+    (("poisson2d_p1_h128_nmax100", {}), -3, 8),
+    (((16, 16, 16), dict(kind="poisson", nmax=64)), -2, 8),
+    (("helmholtz2d_p1_h64_nmax100", {}), -2, 8),
+    (((16, 16, 16), dict(kind="helmholtz", nmax=64)), -2, 8),
+]
+
+
+@pytest.mark.parametrize("name,swlevel,swsize", CASES)
+@pytest.mark.parametrize("tol", [1e-2, 1e-6, 1e-10])
+def test_compressed_ldiv_accuracy(hs, name, swlevel, swsize, tol):
+    from oracle import hs_oracle as O, hs_oracle_lr as OL
+
+    P = prepare(hs, name[0], rhs="randn", **name[1])
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=swlevel, swsize=swsize, atol=tol, rtol=tol)
+    x = hs.ldiv(F, P["b"])
+    xr = spla.splu(P["A"]).solve(P["b"])
+    Fo = OL.factor(P["A"], P["ond"], P["ond_loc"], swlevel=swlevel, swsize=swsize, atol=tol, rtol=tol)
+    xo = O.ldiv(Fo, P["b"])
+    e_gpu, e_orc = relerr(x, xr), relerr(xo, xr)
+    assert hs.maxrank(F) > 0  # something was compressed (factornode.jl:49-57)
+    assert OL.maxrank(Fo) > 0
+    # both are O(tol)-accurate preconditioners (the oracle truncates Abi/Aib by QRCP before D^-1 is applied, the
+    # product truncates Abi*U^-1 / L^-1*P*Aib by a sketched LU): within 10x of each other or of the tolerance
+    assert e_gpu <= max(10 * e_orc, 100 * tol), (e_gpu, e_orc)
+    print(f"tol={tol:g} err(product)={e_gpu:.2e} err(oracle)={e_orc:.2e} maxrank {hs.maxrank(F)} / {OL.maxrank(Fo)}")
+    # ranks revealed by the two factorizations agree up to the slack of the rank rule
+    assert hs.maxrank(F) <= 2 * OL.maxrank(Fo) + 16
+
+
+@pytest.mark.parametrize("name,swlevel,swsize", CASES[:3])
+def test_compressed_transforms_vs_dense(hs, name, swlevel, swsize):
+    """Reconstructed C*Z of every compressed front is within tol of the dense Gauss transform."""
+    tol = 1e-6
+    P = prepare(hs, name[0], **name[1])
+    Fd = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0)
+    Fc = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=swlevel, swsize=swsize, atol=tol, rtol=tol)
+    ncomp = 0
+    for node in range(Fc.nnodes):
+        comp, rl, rr = Fc.node_ranks(node)
+        if not comp:
+            assert (rl, rr) == (0, 0)
+            continue
+        ncomp += 1
+        bd, bc = Fd.node_blocks(node), Fc.node_blocks(node)
+        for key, r in (("Lbi", rl), ("Uib", rr)):
+            D, Cc = bd[key], bc[key]
+            scale = max(np.abs(D).max(), 1e-300)
+            assert np.abs(D - Cc).max() <= 200 * tol * max(scale, 1.0), (node, key, r)
+            assert r <= min(D.shape)
+    assert ncomp > 0
+
+
+def test_compressed_gmres_iterations(hs):
+    """rungmres.jl scenario: GMRES right-preconditioned by a loose-tolerance compressed factorization."""
+    from oracle import hs_oracle as O, hs_oracle_lr as OL
+
+    P = prepare(hs, (16, 16, 16), kind="poisson", nmax=64, rhs="randn")
+    tol = 1e-2
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=-3, swsize=8, atol=tol, rtol=tol)
+    x, ch = hs.gmres(P["A"], P["b"], Pr=F, reltol=1e-9, restart=30, maxiter=30, log=True)
+    assert ch["isconverged"]
+    assert relerr(P["A"] @ x, P["b"]) < 1e-8
+    Fo = OL.factor(P["A"], P["ond"], P["ond_loc"], swlevel=-3, swsize=8, atol=tol, rtol=tol)
+    cnt = [0]
+
+    def prec(v):
+        cnt[0] += 1
+        return O.ldiv(Fo, v)
+
+    M = spla.LinearOperator(P["A"].shape, matvec=prec, dtype=P["A"].dtype)
+    xo, info = spla.gmres(P["A"], P["b"], M=M, rtol=1e-9, restart=30, maxiter=30)
+    assert info == 0
+    assert ch["iters"] <= cnt[0] + 3
+
+
+def test_compressed_refactor_and_multirhs(hs):
+    P = prepare(hs, "poisson2d_p1_h64_nmax100", rhs="randn")
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=-2, swsize=8, atol=1e-8, rtol=1e-8)
+    B = np.random.default_rng(0).standard_normal((P["A"].shape[0], 3))
+    X = hs.ldiv(F, B)
+    Xr = spla.splu(P["A"]).solve(B)
+    assert relerr(X, Xr) < 1e-5
+    for j in range(3):
+        assert relerr(hs.ldiv(F, B[:, j]), X[:, j]) < 1e-12
