@@ -173,7 +173,9 @@ struct hs_handle {
   bool sb_kept = false;
   bool numeric_open = false, factored = false;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;  // high-priority side stream for look-ahead panels
+  hipStream_t stream2 = nullptr;    // side stream for look-ahead panels (own compute units, or high priority)
+  hipStream_t stream_la = nullptr;  // CU-masked pair for the look-ahead schedule of a lone front: stream_la = every CU
+  hipStream_t stream2m = nullptr;   // but a reserved few, stream2m = the reserved ones
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Profiler prof;
   void* d_lr_t = nullptr;     // low-rank apply workspace
@@ -199,6 +201,8 @@ static void free_handle(hs_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  if (h->stream_la) (void)hipStreamDestroy(h->stream_la);
+  if (h->stream2m) (void)hipStreamDestroy(h->stream2m);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -496,11 +500,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     }
 
     HS_HIP(hipStreamCreate(&h->stream));
-    {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
-      if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess) h->stream2 = nullptr;
-    }
+    hs_create_lookahead_streams(&h->stream_la, &h->stream2m, &h->stream2);
     HS_HIP(hipEventCreate(&h->ev0));
     HS_HIP(hipEventCreate(&h->ev1));
     dmalloc(&h->d_fac, fac * sizeof(T), "the factors (LF/UR)");
@@ -716,10 +716,11 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     launch_gather<T>(dn, nb_, L.maxm, h->d_colptr, h->d_rowval, (const T*)h->d_nz, h->d_own, h->d_pos, s);
     launch_scatter<T>(dn, dsc_all + L.sc_off, (int)L.sc_cnt, L.maxnbc, s);
     h->prof.end(ea, HS_CAT_ASSEMBLE, s);
-    Sched<T> sch{dn, nb_, L.maxni, L.maxnb, L.maxm, s, &h->prof, L.h_ni.data(), L.h_nb.data(), h->stream2};
+    Sched<T> sch{dn, nb_, L.maxni, L.maxnb, L.maxm, s, &h->prof, L.h_ni.data(), L.h_nb.data(), h->stream2, 0, h->stream_la, h->stream2m};
     sch.factor_fronts();
     compress_level<T>(h, lv);
-    if (h->opts.profile) {  // per-level wall time (HS_VERBOSE_LEVELS=1 prints it at hs_numeric_end)
+    static const bool lvl_env = getenv("HS_VERBOSE_LEVELS") != nullptr;
+    if (h->opts.profile || lvl_env) {  // per-level wall time (HS_VERBOSE_LEVELS=1 prints it at hs_numeric_end)
       hipEvent_t e = nullptr;
       (void)hipEventCreate(&e);
       (void)hipEventRecord(e, s);

@@ -136,6 +136,13 @@ void launch_gemm_probs(const GemmProb<T>* dprobs, int nprob, int maxM, int maxN,
 template <class T>
 void launch_tournament_round(const NodeDesc<T>* dnodes, int nbatch, int pb, int round, int maxchunks, hipStream_t s);
 template <class T>
+void launch_tournament_stage(const NodeDesc<T>* dnodes, int nbatch, int pb, int stage, int maxblocks, hipStream_t s);
+int hs_tour_block_rows(bool is_complex);
+// Streams of the look-ahead schedule (hs_sched.h): *side = high-priority stream on every CU; the masked pair
+// (*side_masked owns HS_LA_SIDE_CUS compute units, default 32, *la every other one) is used for a lone front.
+// Any of them may come back null (the schedule then falls back: no reservation / no look-ahead).
+void hs_create_lookahead_streams(hipStream_t* la, hipStream_t* side_masked, hipStream_t* side);  // rows one workgroup of a tournament stage reduces to 32 nominees
+template <class T>
 void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, hipStream_t s);
 template <class T>
 void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, hipStream_t s);

@@ -64,6 +64,8 @@ struct Sched {
   const int* h_nb;
   hipStream_t s2 = nullptr;  // optional high-priority side stream: look-ahead panels for large fronts
   int maxpiv = 0;            // largest pivot-candidate row limit in the batch (0: = maxni)
+  hipStream_t s_la = nullptr;  // optional CU-masked pair for the look-ahead schedule: s_la = every CU but a reserved
+  hipStream_t s2m = nullptr;   // few, s2m = the reserved ones
 
   // HS_DEBUG_SYNC=1: synchronise after every launch and report the first failing one (diagnostics only)
   void dbg(const char* what, int a = 0, int b = 0, int c = 0, int d = 0) {
@@ -78,6 +80,10 @@ struct Sched {
     if (e != hipSuccess) fprintf(stderr, "[hs debug] %s(%d,%d,%d,%d) nbatch=%d maxni=%d maxnb=%d maxm=%d -> %s\n", what, a, b, c, d, nbatch, maxni, maxnb, maxm, hipGetErrorString(e));
   }
 
+  static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+  }
   int rows_of(int mat) const { return mat == HS_MAT_LF ? maxm : (mat == HS_MAT_UR ? maxni : maxnb); }
   int cols_of(int mat) const { return mat == HS_MAT_LF ? maxni : maxnb; }
 
@@ -103,14 +109,29 @@ struct Sched {
   void panel(int pb) {
     int c0 = pb * HS_PB;
     if (c0 >= maxni) return;
-    int cnt = (maxpiv > 0 ? maxpiv : maxni) - c0, nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
+    // pivot search: 256-row chunks (4 waves, modest registers: finds a slot next to a running GEMM) by default;
+    // HS_TOUR_BIG=1 selects the 1024-row-chunk kernel (fewer stages, but a workgroup needs a whole idle CU)
+    static const int big = env_int("HS_TOUR_BIG", 0);
     hipEvent_t e0 = pf->begin(s);
-    for (int round = 0;; ++round) {
-      launch_tournament_round<T>(dn, nbatch, pb, round, nch, s);
-      dbg("tournament", pb, round, nch);
-      if (nch == 1) break;
-      cnt = nch * HS_PB;
-      nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
+    if (big) {
+      const int BR = hs_tour_block_rows(sizeof(T) == 16);
+      int cnt = (maxpiv > 0 ? maxpiv : maxni) - c0, nblk = (cnt + BR - 1) / BR;
+      for (int stage = 0;; ++stage) {
+        launch_tournament_stage<T>(dn, nbatch, pb, stage, nblk, s);
+        dbg("tournament", pb, stage, nblk);
+        if (nblk == 1) break;
+        cnt = nblk * HS_PB;
+        nblk = (cnt + BR - 1) / BR;
+      }
+    } else {
+      int cnt = (maxpiv > 0 ? maxpiv : maxni) - c0, nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
+      for (int round = 0;; ++round) {
+        launch_tournament_round<T>(dn, nbatch, pb, round, nch, s);
+        dbg("tournament", pb, round, nch);
+        if (nch == 1) break;
+        cnt = nch * HS_PB;
+        nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
+      }
     }
     launch_panel_pivot<T>(dn, nbatch, pb, s);
     dbg("panel_pivot", pb);
@@ -168,41 +189,63 @@ struct Sched {
   // chip; at Poisson 128^3 the root front spent more time in it than in its GEMMs).  Block column
   // j+1 is brought up to date first and factored on the side stream while the main stream applies
   // block j to the rest of the trailing matrix and to Aib.  Left swaps are applied once at the end.
-  static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-  }
   void factor_fronts_lookahead(int NB) {
+    // `mn` drives the trailing updates, `side` the panel of the next block column.  When the handle owns
+    // CU-masked streams (s_la: all CUs but a reserved few; s2: the reserved ones) the two never compete
+    // for a compute unit: without the reservation every one of the ~10 dependent tiny kernels of a
+    // 32-column panel step waited for a GEMM workgroup to retire, which doubled the panel chain.
+    Sched<T> mn = *this;
     Sched<T> side = *this;
-    side.s = s2;
-    side.s2 = nullptr;
+    hipStream_t s_la = (nbatch == 1 && s2m) ? this->s_la : nullptr;  // reservation pays for a lone front (the root):
+    hipStream_t s2 = s_la ? s2m : this->s2;                          // batched fronts keep every CU on the GEMMs
     hipEvent_t ev_main, ev_side;
     (void)hipEventCreateWithFlags(&ev_main, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ev_side, hipEventDisableTiming);
-    lu_rec(0, NB);
+    if (s_la) {
+      mn.s = s_la;
+      (void)hipEventRecord(ev_main, s);
+      (void)hipStreamWaitEvent(s_la, ev_main, 0);
+    }
+    mn.s2 = nullptr;
+    mn.s_la = nullptr;
+    side.s = s2;
+    side.s2 = nullptr;
+    side.s_la = nullptr;
+    if (s_la) {
+      (void)hipStreamWaitEvent(s2, ev_main, 0);
+      side.lu_rec(0, NB);
+      (void)hipEventRecord(ev_side, s2);
+      (void)hipStreamWaitEvent(mn.s, ev_side, 0);
+    } else {
+      mn.lu_rec(0, NB);
+    }
     for (int c0 = 0; c0 < maxni; c0 += NB) {
       const int c1 = c0 + NB, c2 = c1 + NB;
       const bool has_next = c1 < maxni;
       if (has_next) {
-        laswp(HS_MAT_LF, c1, c2, c0, c1);
-        trsm_rec(HS_MAT_LF, c0, c1, c1, c2);
-        gemm(HS_MAT_LF, HS_MAT_LF, c1, HS_BIG, c1, c2, c0, c1);
-        (void)hipEventRecord(ev_main, s);
+        mn.laswp(HS_MAT_LF, c1, c2, c0, c1);
+        mn.trsm_rec(HS_MAT_LF, c0, c1, c1, c2);
+        mn.gemm(HS_MAT_LF, HS_MAT_LF, c1, HS_BIG, c1, c2, c0, c1);
+        (void)hipEventRecord(ev_main, mn.s);
         (void)hipStreamWaitEvent(s2, ev_main, 0);
         side.lu_rec(c1, c2);
         (void)hipEventRecord(ev_side, s2);
-        laswp(HS_MAT_LF, c2, HS_BIG, c0, c1);
-        trsm_rec(HS_MAT_LF, c0, c1, c2, HS_BIG);
-        gemm(HS_MAT_LF, HS_MAT_LF, c1, HS_BIG, c2, HS_BIG, c0, c1);
+        mn.laswp(HS_MAT_LF, c2, HS_BIG, c0, c1);
+        mn.trsm_rec(HS_MAT_LF, c0, c1, c2, HS_BIG);
+        mn.gemm(HS_MAT_LF, HS_MAT_LF, c1, HS_BIG, c2, HS_BIG, c0, c1);
       }
       if (maxnb > 0) {
-        laswp(HS_MAT_UR, 0, HS_BIG, c0, c1);
-        trsm_rec(HS_MAT_UR, c0, c1, 0, HS_BIG);
-        gemm(HS_MAT_UR, HS_MAT_UR, c1, HS_BIG, 0, HS_BIG, c0, c1);
+        mn.laswp(HS_MAT_UR, 0, HS_BIG, c0, c1);
+        mn.trsm_rec(HS_MAT_UR, c0, c1, 0, HS_BIG);
+        mn.gemm(HS_MAT_UR, HS_MAT_UR, c1, HS_BIG, 0, HS_BIG, c0, c1);
       }
-      if (has_next) (void)hipStreamWaitEvent(s, ev_side, 0);
+      if (has_next) (void)hipStreamWaitEvent(mn.s, ev_side, 0);
     }
-    for (int c0 = 0; c0 + NB < maxni; c0 += NB) laswp(HS_MAT_LF, c0, c0 + NB, c0 + NB, HS_BIG);
+    for (int c0 = 0; c0 + NB < maxni; c0 += NB) mn.laswp(HS_MAT_LF, c0, c0 + NB, c0 + NB, HS_BIG);
+    if (s_la) {  // hand back to the handle's stream: the Schur update may use every CU again
+      (void)hipEventRecord(ev_main, s_la);
+      (void)hipStreamWaitEvent(s, ev_main, 0);
+    }
     if (maxnb > 0) gemm(HS_MAT_SB, HS_MAT_UR, 0, HS_BIG, 0, HS_BIG, 0, HS_BIG);
     (void)hipEventDestroy(ev_main);
     (void)hipEventDestroy(ev_side);

@@ -2,6 +2,7 @@
 // They drive exactly the kernels hs_factor_* uses, on caller-supplied dense data, so every kernel
 // can be checked against the oracle in isolation.
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "../../include/hs_kernels.h"
@@ -122,11 +123,18 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  CK(hipEventRecord(e0, 0));
-  launch_init_fronts<T>(dn, (int)count, (int)ni, 0);
-  Sched<T> sch{dn, (int)count, (int)ni, (int)nb, m, 0, &prof, nullptr, nullptr};
+  // same stream set-up as hs_analyze: a main stream and a high-priority side stream for look-ahead panels
+  hipStream_t s_main = nullptr, s_side = nullptr, s_la = nullptr, s_sidem = nullptr;
+  CK(hipStreamCreate(&s_main));
+  hs_create_lookahead_streams(&s_la, &s_sidem, &s_side);
+  CK(hipEventRecord(e0, s_main));
+  launch_init_fronts<T>(dn, (int)count, (int)ni, s_main);
+  Sched<T> sch{dn, (int)count, (int)ni, (int)nb, m, s_main, &prof, nullptr, nullptr, s_side, 0, s_la, s_sidem};
+  const auto h0 = std::chrono::steady_clock::now();
   sch.factor_fronts();
-  CK(hipEventRecord(e1, 0));
+  CK(hipEventRecord(e1, s_main));
+  if (getenv("HS_HOOK_VERBOSE"))
+    fprintf(stderr, "[hook] host enqueue time %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count());
   CK(hipEventSynchronize(e1));
   float ms = 0.f;
   CK(hipEventElapsedTime(&ms, e0, e1));
@@ -147,6 +155,10 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(s_main);
+  if (s_side) (void)hipStreamDestroy(s_side);
+  if (s_la) (void)hipStreamDestroy(s_la);
+  if (s_sidem) (void)hipStreamDestroy(s_sidem);
   (void)hipFree(dbuf);
   (void)hipFree(dint);
   (void)hipFree(dn);

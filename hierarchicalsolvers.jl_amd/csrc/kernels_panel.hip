@@ -54,6 +54,12 @@ __device__ inline unsigned long long wave_max_u64(unsigned long long v) {
   return m;
 }
 
+__device__ inline double lane_bcast(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_readlane(hi, lane), __builtin_amdgcn_readlane(lo, lane));
+}
+__device__ inline cplx lane_bcast(cplx v, int lane) { return {lane_bcast(v.re, lane), lane_bcast(v.im, lane)}; }
+
 template <class T>
 __global__ __launch_bounds__(HS_CHUNK) void tournament_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int round) {
   const NodeDesc<T> nd = nodes[blockIdx.y];
@@ -223,41 +229,76 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
     s_iu[i][j] = id;
   }
   __syncthreads();
-  // unpivoted LU (pivot order fixed by the tournament); the same row operations applied to I give inv(L)
-  for (int k = 0; k < HS_PB; ++k) {
-    const T piv = s_a[k][k];
-    const bool zero_piv = (Scal<T>::abs1(piv) == 0.0);
-    if (t < HS_PB && t > k && !zero_piv) s_a[t][k] = s_a[t][k] / piv;
-    if (zero_piv && t == 0 && k < w) {
-      int old = *nd.info;
-      if (old == 0 || old > c0 + k + 1) *nd.info = c0 + k + 1;
+  // unpivoted LU (pivot order fixed by the tournament); the same row operations applied to I give inv(L).
+  // ONE wave does the 32 dependent steps with the rows in registers (lane i = row i; the pivot row comes
+  // from lane k through v_readlane, k a compile-time constant): no barriers, no LDS traffic inside the
+  // chain -- the 128 workgroup barriers of the previous LDS formulation were 2/3 of this kernel's time.
+  if (t < 64) {
+    const int i = t & 31;
+    T ar[HS_PB], il[HS_PB];
+#pragma clang loop unroll(full)
+    for (int j = 0; j < HS_PB; ++j) {
+      ar[j] = s_a[i][j];
+      il[j] = (i == j) ? Scal<T>::one() : Scal<T>::zero();
     }
-    __syncthreads();
-    if (!zero_piv) {
-      for (int e = t; e < HS_PB * HS_PB; e += 256) {
-        int i = e & 31, j = e >> 5;
+    int bad = 0;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < HS_PB; ++k) {
+      const T piv = lane_bcast(ar[k], k);
+      if (Scal<T>::abs1(piv) == 0.0) {  // wave-uniform
+        if (bad == 0 && k < w) bad = c0 + k + 1;
+      } else {
+        const T rp = Scal<T>::one() / piv;
+        T l = Scal<T>::zero();
         if (i > k) {
+          l = ar[k] * rp;
+          ar[k] = l;
+        }
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j) {
           if (j > k)
-            s_a[i][j] = Scal<T>::fnma(s_a[i][k], s_a[k][j], s_a[i][j]);
+            ar[j] = Scal<T>::fnma(l, lane_bcast(ar[j], k), ar[j]);
           else
-            s_il[i][j] = Scal<T>::fnma(s_a[i][k], s_il[k][j], s_il[i][j]);
+            il[j] = Scal<T>::fnma(l, lane_bcast(il[j], k), il[j]);
         }
       }
     }
-    __syncthreads();
-  }
-  // inv(U) by back substitution in rank-1 form (zero pivots are treated as 1: the front is already flagged)
-  for (int p = HS_PB - 1; p >= 0; --p) {
-    T d = s_a[p][p];
-    if (Scal<T>::abs1(d) == 0.0) d = Scal<T>::one();
-    if (t < HS_PB && t >= p) s_iu[p][t] = s_iu[p][t] / d;
-    __syncthreads();
-    for (int e = t; e < HS_PB * HS_PB; e += 256) {
-      int i = e & 31, j = e >> 5;
-      if (i < p && j >= p) s_iu[i][j] = Scal<T>::fnma(s_a[i][p], s_iu[p][j], s_iu[i][j]);
+    if (bad && t == 0) {
+      int old = *nd.info;
+      if (old == 0 || old > bad) *nd.info = bad;
     }
-    __syncthreads();
+    if (t < HS_PB) {
+#pragma clang loop unroll(full)
+      for (int j = 0; j < HS_PB; ++j) {
+        s_a[i][j] = ar[j];
+        s_il[i][j] = il[j];
+      }
+    }
+    // inv(U) by back substitution in rank-1 form (zero pivots are treated as 1: the front is already flagged):
+    // lane i owns row i of inv(U) and of U; row p comes from lane p
+#pragma clang loop unroll(full)
+    for (int j = 0; j < HS_PB; ++j) il[j] = (i == j) ? Scal<T>::one() : Scal<T>::zero();
+#pragma clang loop unroll(full)
+    for (int p = HS_PB - 1; p >= 0; --p) {
+      T d = lane_bcast(ar[p], p);
+      if (Scal<T>::abs1(d) == 0.0) d = Scal<T>::one();
+      const T rd = Scal<T>::one() / d;
+      const T u = (i < p) ? ar[p] : Scal<T>::zero();
+#pragma clang loop unroll(full)
+      for (int j = 0; j < HS_PB; ++j) {
+        if (j >= p) {
+          if (i == p) il[j] = il[j] * rd;
+          const T rowp = lane_bcast(il[j], p);
+          il[j] = Scal<T>::fnma(u, rowp, il[j]);
+        }
+      }
+    }
+    if (t < HS_PB) {
+#pragma clang loop unroll(full)
+      for (int j = 0; j < HS_PB; ++j) s_iu[i][j] = il[j];
+    }
   }
+  __syncthreads();
   for (int e = t; e < HS_PB * HS_PB; e += 256) {
     int i = e & 31, j = e >> 5;
     if (i < w && j < w) nd.LF[(size_t)(c0 + i) + (size_t)(c0 + j) * nd.ldl] = s_a[i][j];
