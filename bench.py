@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="poisson3d_32")
     ap.add_argument("--no-profile", action="store_true", help="skip the extra profiled step that feeds `roofline`")
+    ap.add_argument("--swlevel", type=int, default=0, help="compress fronts at tree levels <= swlevel (<0: from the leaves); 0 = exact")
+    ap.add_argument("--swsize", type=int, default=8)
+    ap.add_argument("--tol", type=float, default=1e-6, help="atol = rtol of the compressed fronts")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,7 +111,8 @@ def main():
     t_host = time.perf_counter() - t0
     is_c = np.iscomplexobj(Ap.data)
 
-    S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, swlevel=0)
+    fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol) if args.swlevel != 0 else dict(swlevel=0)
+    S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, **fopts)
     b_dev0 = torch.from_numpy(np.ascontiguousarray(bp)).to(dev)
     b_dev = torch.empty_like(b_dev0)
 
@@ -149,7 +153,7 @@ def main():
         S.backend._h = None
         del S
         torch.cuda.empty_cache()
-        S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, swlevel=0, profile=True)
+        S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, profile=True, **fopts)
         S.numeric()
         sp_ = S.stats()
         if sp_["t_gemm"] > 0:
@@ -177,7 +181,7 @@ def main():
     if rank == 0:
         flops = st["flops_factor"] if world == 1 else None
         out = {
-            "metric": "factorize+solve time, synthetic 3D problem, exact (swlevel=0) nested-dissection elimination",
+            "metric": "factorize+solve time, synthetic 3D problem, " + ("exact (swlevel=0)" if args.swlevel == 0 else "compressed (low-rank off-diagonal blocks)") + " nested-dissection elimination",
             "value": per_step,
             "unit": "s",
             "n_gpus": world,
@@ -191,9 +195,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "n": int(Ap.shape[0]), "nnz": int(Ap.nnz), "tree_nodes": int(st["nnodes"]),
                        "tree_depth": int(st["nlevels"]), "max_front": [int(st["max_ni"]), int(st["max_nb"])], "nrhs": 1,
-                       "compression": "none (swlevel=0)", "partition": f"subtree-per-rank x{world}"},
+                       "compression": "none (swlevel=0)" if args.swlevel == 0 else f"low-rank Gauss transforms, swlevel={args.swlevel} swsize={args.swsize} atol=rtol={args.tol:g}",
+                       "partition": f"subtree-per-rank x{world}"},
             "factor_s": st["t_total"],
             "residual": res,
+            "maxrank": int(S.backend.L.hs_maxrank(S.backend._h)) if getattr(S.backend, "_h", None) else None,
             "host_symbolic_s": t_host,
         }
         if flops:

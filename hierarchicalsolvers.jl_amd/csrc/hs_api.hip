@@ -119,6 +119,7 @@ struct NodeH {
   bool compressed = false;  // level <= swlevel && |bnd| >= swsize (factorization.jl:15): low-rank Gauss transforms
   void* lrL = nullptr;      // LowRank<T>* of Lbi = Abi*U^-1  (nb x ni)
   void* lrR = nullptr;      // LowRank<T>* of Uib = L^-1*P*Aib (ni x nb)
+  int last_rL = 0, last_rR = 0;  // ranks found by the previous factorization (initial sketch width of the next one)
 };
 
 struct LevelH {
@@ -130,6 +131,8 @@ struct LevelH {
   size_t desc_off = 0;              // first NodeDesc / SolveNode of this level (owned fronts only)
   size_t sc_off = 0, sc_cnt = 0;    // ScatterDesc range
   std::vector<int> h_ni, h_nb;
+  int ndense = 0;                          // the first ndense entries of `mine` are dense fronts (one batch), the rest compressed
+  int dmaxni = 0, dmaxnb = 0, dmaxm = 0;   // extents of the dense batch
 };
 
 struct Exchange {
@@ -178,6 +181,8 @@ struct hs_handle {
   hipStream_t stream2m = nullptr;   // but a reserved few, stream2m = the reserved ones
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Profiler prof;
+  void* d_cdesc = nullptr;    // private descriptors (3 per front) of the compressed fronts being eliminated
+  size_t cdesc_cap = 0;
   void* d_lr_t = nullptr;     // low-rank apply workspace
   void* d_lr_part = nullptr;
   size_t lr_t_elems = 0, lr_part_elems = 0;
@@ -422,6 +427,29 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     int64_t swlevel = opts.swlevel < 0 ? std::max<int64_t>(nlev + opts.swlevel, 0) : opts.swlevel;
     for (int i = 0; i < h->nreal; ++i)  // compression_flag of factorization.jl:15 (phase 1: low-rank Gauss transforms, hs_compress.h)
       N[i].compressed = (N[i].level <= swlevel) && (N[i].nb >= opts.swsize) && N[i].nb > 0 && N[i].ni > 0 && !N[i].leaf;  // a compressed LEAF keeps dense L, R (factorization.jl:45-59)
+    for (auto& L : h->levels) {  // dense fronts first: they are eliminated as one batch, compressed fronts one by one
+      std::vector<int> ord;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int id : L.mine)
+          if ((int)N[id].compressed == pass) ord.push_back(id);
+      L.mine = ord;
+      L.h_ni.clear();
+      L.h_nb.clear();
+      L.ndense = 0;
+      L.dmaxni = L.dmaxnb = L.dmaxm = 0;
+      for (size_t k = 0; k < L.mine.size(); ++k) {
+        NodeH& x = N[L.mine[k]];
+        x.batch_pos = (int)k;
+        L.h_ni.push_back(x.ni);
+        L.h_nb.push_back(x.nb);
+        if (!x.compressed) {
+          L.ndense = (int)k + 1;
+          L.dmaxni = std::max(L.dmaxni, x.ni);
+          L.dmaxnb = std::max(L.dmaxnb, x.nb);
+          L.dmaxm = std::max(L.dmaxm, x.m);
+        }
+      }
+    }
 
     // ---- HBM layout (owned fronts: LF/UR/inv; owned + ghost fronts: SB) ------------------------------
     size_t fac = 0, inv = 0, ints = h->fidx_host.size(), tmpi = 0;
@@ -716,9 +744,11 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     launch_gather<T>(dn, nb_, L.maxm, h->d_colptr, h->d_rowval, (const T*)h->d_nz, h->d_own, h->d_pos, s);
     launch_scatter<T>(dn, dsc_all + L.sc_off, (int)L.sc_cnt, L.maxnbc, s);
     h->prof.end(ea, HS_CAT_ASSEMBLE, s);
-    Sched<T> sch{dn, nb_, L.maxni, L.maxnb, L.maxm, s, &h->prof, L.h_ni.data(), L.h_nb.data(), h->stream2, 0, h->stream_la, h->stream2m};
-    sch.factor_fronts();
-    compress_level<T>(h, lv);
+    if (L.ndense > 0) {
+      Sched<T> sch{dn, L.ndense, L.dmaxni, L.dmaxnb, L.dmaxm, s, &h->prof, L.h_ni.data(), L.h_nb.data(), h->stream2, 0, h->stream_la, h->stream2m};
+      sch.factor_fronts();
+    }
+    if (nb_ > L.ndense) factor_compressed_level<T>(h, L.mine.data() + L.ndense, nb_ - L.ndense, dn + L.ndense);  // hs_compress.h
     static const bool lvl_env = getenv("HS_VERBOSE_LEVELS") != nullptr;
     if (h->opts.profile || lvl_env) {  // per-level wall time (HS_VERBOSE_LEVELS=1 prints it at hs_numeric_end)
       hipEvent_t e = nullptr;

@@ -106,7 +106,7 @@ struct GemmOp {
   int r0, r1;      // C rows   (A rows are the same, shifted by ni when C is SB)
   int c0, c1;      // C cols = B cols
   int k0, k1;      // A cols = B rows (always inside [0, ni))
-  int ainv;        // 1: A = invL[r0/32] (32x32), C = A*B in place on rows [r0, r0+32): the TRSM base case
+  int ainv;        // 1: A = invL[r0/32] (32x32), C = A*B in place on rows [r0, r0+32): the TRSM base case; 2: A = invU[r0/32]
 };
 
 // plain problem (test hooks, root Schur, compressed path)

@@ -9,9 +9,43 @@ struct LowRank {
   int* rperm = nullptr; // rows: pivoted row i of Lp is original row rperm[i]
   T* Z = nullptr;       // r x cols (ld = ldz)
   int rows = 0, cols = 0, k = 0, r = 0, ldp = 0, ldz = 0;
+  T* Cd = nullptr;      // optional dense C (rows x r, ld = ldc) in ORIGINAL row order; when set it replaces P'*trap(Lp)
+  int ldc = 0;
 };
 
 template <class T>
 int lowrank_compress(T* X, int ldx, int rows, int cols, double atol, double rtol, int kinit, uint64_t seed, hipStream_t s, LowRank<T>* out);
 template <class T>
 void lowrank_free(LowRank<T>& lr);
+// hs_lowrank_batch.hip: the same compression for a batch of independent blocks (one grouped launch per stage)
+template <class T>
+struct LowRankJob {
+  T* X;            // rows x cols, ld ldx; destroyed
+  int ldx, rows, cols;
+  int kinit;       // initial sketch width (<= 0: 128)
+  uint64_t seed;
+  LowRank<T>* out;
+  int k;           // work: current sketch width
+};
+template <class T>
+int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s);
+// hs_lrdense.hip
+template <class T>
+void lowrank_expand(LowRank<T>& lr, hipStream_t s);  // fills Cd from the trapezoid form
+template <class T>
+void launch_lr_dense(const T* C, int ldc, int rows, int r, const T* t, T* dst, const int* didx, hipStream_t s);
+template <class T>
+struct RtrsmJob {
+  T* X;        // r x n (ld ldx): right-hand side, consumed
+  int ldx;
+  T* Xout;     // r x n (ld ldo): X * U^-1
+  int ldo;
+  const T* LF;   // U = upper triangle of LF[0:n, 0:n] (ld ldl)
+  int ldl;
+  const T* invU;  // inverted 32x32 diagonal blocks of U
+  int n, r;
+};
+template <class T>
+int rtrsm_upper_batch(const RtrsmJob<T>* jobs, int nj, hipStream_t s, void** dprobs_out);
+template <class T>
+int rtrsm_upper(T* X, int ldx, T* Xout, int ldo, const T* LF, int ldl, const T* invU, int n, int r, hipStream_t s, void** dprobs_out);

@@ -64,6 +64,7 @@ void lowrank_free(LowRank<T>& lr) {
   if (lr.Lp) (void)hipFree(lr.Lp);
   if (lr.Z) (void)hipFree(lr.Z);
   if (lr.rperm) (void)hipFree(lr.rperm);
+  if (lr.Cd) (void)hipFree(lr.Cd);
   lr = LowRank<T>();
 }
 

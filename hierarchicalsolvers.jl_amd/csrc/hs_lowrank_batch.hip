@@ -1,0 +1,267 @@
+// hs_lowrank_batch.hip -- the randomized row ID of hs_lowrank.hip for a BATCH of independent blocks.
+//
+// Same algorithm per block (sketch Y = X*Omega, pivoted LU of Y over all rows, rank from |u_jj|, Z = L11^-1 (P X)[:r,:]),
+// but every stage is one grouped launch over the blocks: the pivoted LU of a sketch is a chain of ~10 dependent
+// tiny kernels per 32 columns, and 16 such chains run back to back (the Gauss transforms of 8 fronts) were the
+// largest part of a compressed level.  Blocks whose rank reaches their sketch width are redone with twice the
+// width while the others wait (they are finished); `kinit` of a block normally comes from the rank it had in the
+// previous factorization, so the usual number of passes is one.
+//
+// Role in the reference: `pqrfact` inside `_lgauss_transform` / `_rgauss_transform` (src/factorization.jl:171-182).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "hs_sched.h"
+#include "hs_lowrank.h"
+
+namespace {
+
+__device__ inline uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void randn_fill_kernel(double* out, size_t n, uint64_t seed) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t a = mix64(seed ^ (i * 0xD1342543DE82EF95ull)), b = mix64(a);
+  double u1 = ((a >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0, 1]
+  double u2 = (b >> 11) * (1.0 / 9007199254740992.0);
+  out[i] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
+template <class T>
+struct DiagJob {
+  const T* LU;
+  int ld, k;
+  double* out;
+};
+template <class T>
+__global__ __launch_bounds__(64) void absdiag_batch_kernel(const DiagJob<T>* __restrict__ jobs) {
+  const DiagJob<T> j = jobs[blockIdx.y];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c < j.k) j.out[c] = Scal<T>::abs1(j.LU[(size_t)c + (size_t)c * j.ld]);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void copy_top_rows_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int r) {
+  const int c = blockIdx.x;
+  for (int i = threadIdx.x; i < r; i += 256) dst[(size_t)i + (size_t)c * ldd] = src[(size_t)i + (size_t)c * lds];
+}
+
+struct Guard {  // frees what it was given, whatever the exit path
+  std::vector<void*> p;
+  ~Guard() {
+    for (void* q : p)
+      if (q) (void)hipFree(q);
+  }
+  template <class U>
+  hipError_t alloc(U** out, size_t bytes) {
+    *out = nullptr;
+    hipError_t e = hipMalloc((void**)out, bytes ? bytes : 256);
+    if (e == hipSuccess) p.push_back(*out);
+    return e;
+  }
+};
+
+}  // namespace
+
+#define LRB_HIP(call)                                                         \
+  do {                                                                        \
+    hipError_t e__ = (call);                                                  \
+    if (e__ != hipSuccess) {                                                  \
+      hs_set_error(-6, 0, "%s failed: %s", #call, hipGetErrorString(e__));    \
+      return -6;                                                              \
+    }                                                                         \
+  } while (0)
+
+template <class T>
+int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s) {
+  std::vector<int> todo;
+  for (int i = 0; i < njobs; ++i) {
+    LowRankJob<T>& J = jobs[i];
+    *J.out = LowRank<T>();
+    J.out->rows = J.rows;
+    J.out->cols = J.cols;
+    if (J.rows <= 0 || J.cols <= 0) continue;
+    const int kmax = std::min(J.rows, J.cols);
+    J.k = std::min(std::max(32, J.kinit > 0 ? J.kinit : 128), kmax);
+    todo.push_back(i);
+  }
+  Profiler prof;  // off
+  for (int pass = 0; !todo.empty(); ++pass) {
+    const int nj = (int)todo.size();
+    Guard g;  // temporaries of this pass
+    // ---- layout of the temporaries: Omega, inverse blocks, ints, diagonals ---------------------------------------
+    std::vector<size_t> offOm(nj), offInv(nj), offInt(nj), offDg(nj);
+    size_t nOm = 0, nInv = 0, nInt = 0, nDg = 0;
+    int maxk = 0, maxrows = 0, maxcols = 0;
+    for (int a = 0; a < nj; ++a) {
+      const LowRankJob<T>& J = jobs[todo[a]];
+      const int nblk = (J.k + HS_PB - 1) / HS_PB, ncand = ((J.rows + 127) / 128 + 1) * HS_PB;
+      offOm[a] = nOm;
+      nOm += (size_t)J.cols * J.k + 32;
+      offInv[a] = nInv;
+      nInv += (size_t)2 * nblk * HS_PB * HS_PB;
+      offInt[a] = nInt;
+      nInt += (size_t)J.k + J.rows + 2 * ncand + HS_PB + 8;
+      offDg[a] = nDg;
+      nDg += (size_t)J.k;
+      maxk = std::max(maxk, J.k);
+      maxrows = std::max(maxrows, J.rows);
+      maxcols = std::max(maxcols, J.cols);
+    }
+    T *dOm, *dInv;
+    int* dInt;
+    double* dDg;
+    NodeDesc<T>* dn;
+    GemmProb<T>* dgp;
+    DiagJob<T>* ddj;
+    LRB_HIP(g.alloc(&dOm, sizeof(T) * nOm));
+    LRB_HIP(g.alloc(&dInv, sizeof(T) * nInv));
+    LRB_HIP(g.alloc(&dInt, sizeof(int) * nInt));
+    LRB_HIP(g.alloc(&dDg, sizeof(double) * nDg));
+    LRB_HIP(g.alloc(&dn, sizeof(NodeDesc<T>) * nj));
+    LRB_HIP(g.alloc(&dgp, sizeof(GemmProb<T>) * nj));
+    LRB_HIP(g.alloc(&ddj, sizeof(DiagJob<T>) * nj));
+    LRB_HIP(hipMemsetAsync(dInt, 0, sizeof(int) * nInt, s));
+    const size_t nrand = nOm * (sizeof(T) / 8);
+    hipLaunchKernelGGL(randn_fill_kernel, dim3((unsigned)((nrand + 255) / 256)), dim3(256), 0, s, (double*)dOm, nrand,
+                       jobs[todo[0]].seed + 0x1000ull * pass);
+    // ---- per block: the sketch Y (kept: it becomes the packed L\U that holds C), descriptors ------------------------
+    std::vector<NodeDesc<T>> hn(nj);
+    std::vector<GemmProb<T>> hgp(nj);
+    std::vector<DiagJob<T>> hdj(nj);
+    std::vector<T*> Y(nj, nullptr);
+    std::vector<int> ldp(nj);
+    for (int a = 0; a < nj; ++a) {
+      LowRankJob<T>& J = jobs[todo[a]];
+      ldp[a] = (J.rows + 1) / 2 * 2;
+      if (hipMalloc((void**)&Y[a], sizeof(T) * ((size_t)ldp[a] * J.k + 32)) != hipSuccess) {
+        for (T* y : Y)
+          if (y) (void)hipFree(y);
+        hs_set_error(-7, 0, "hipMalloc of a %d x %d sketch failed", J.rows, J.k);
+        return -7;
+      }
+      const int nblk = (J.k + HS_PB - 1) / HS_PB, ncand = ((J.rows + 127) / 128 + 1) * HS_PB;
+      hgp[a] = GemmProb<T>{J.X, dOm + offOm[a], Y[a], J.rows, J.k, J.cols, J.ldx, J.cols, ldp[a]};
+      NodeDesc<T>& d = hn[a];
+      memset(&d, 0, sizeof d);
+      d.LF = Y[a];
+      d.UR = J.X;
+      d.SB = nullptr;
+      d.invL = dInv + offInv[a];
+      d.invU = d.invL + (size_t)nblk * HS_PB * HS_PB;
+      d.ipiv = dInt + offInt[a];
+      d.rperm = d.ipiv + J.k;
+      d.cand0 = d.rperm + J.rows;
+      d.cand1 = d.cand0 + ncand;
+      d.pivlist = d.cand1 + ncand;
+      d.info = d.pivlist + HS_PB;
+      d.ni = J.k; d.nb = J.rows - J.k; d.m = J.rows;
+      d.ldl = ldp[a]; d.ldu = J.ldx; d.lds = 2;
+      d.ni1 = J.k; d.nb1 = J.rows - J.k; d.isleaf = 1; d.node = a;
+      d.pivrows = J.rows;
+      d.finalize();
+      d.mrows[1] = J.k;   // "UR" = X: the TRSM touches its first k rows, the swaps reach every row
+      d.mcols[1] = J.cols;
+      d.mrows[2] = 0;
+      d.mcols[2] = 0;
+      hdj[a] = DiagJob<T>{Y[a], ldp[a], J.k, dDg + offDg[a]};
+    }
+    auto free_Y = [&]() {
+      for (T* y : Y)
+        if (y) (void)hipFree(y);
+    };
+    hipError_t e = hipMemcpyAsync(dn, hn.data(), sizeof(NodeDesc<T>) * nj, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dgp, hgp.data(), sizeof(GemmProb<T>) * nj, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ddj, hdj.data(), sizeof(DiagJob<T>) * nj, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // the sources are host vectors
+    if (e != hipSuccess) {
+      free_Y();
+      hs_set_error(-6, 0, "upload of the compression descriptors failed: %s", hipGetErrorString(e));
+      return -6;
+    }
+    launch_gemm_probs<T>(dgp, nj, maxrows, maxk, 0, s);  // Y = X * Omega, all blocks
+    launch_init_fronts<T>(dn, nj, maxrows, s);
+    Sched<T> sch{dn, nj, maxk, maxcols, maxrows, s, &prof, nullptr, nullptr, nullptr, maxrows};
+    int P2 = HS_PB;
+    while (P2 < maxk) P2 *= 2;
+    sch.lu_rec(0, P2);
+    hipLaunchKernelGGL(absdiag_batch_kernel<T>, dim3((maxk + 63) / 64, nj), dim3(64), 0, s, (const DiagJob<T>*)ddj);
+    std::vector<double> hd(nDg);
+    e = hipMemcpyAsync(hd.data(), dDg, sizeof(double) * nDg, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      free_Y();
+      hs_set_error(-6, 0, "pivoted LU of the sketches failed: %s", hipGetErrorString(e));
+      return -6;
+    }
+    // ---- ranks; blocks whose rank reaches the sketch width go to the next pass with twice the width ---------------
+    std::vector<int> next;
+    std::vector<int> rank(nj, 0);
+    bool any_done = false;
+    for (int a = 0; a < nj; ++a) {
+      LowRankJob<T>& J = jobs[todo[a]];
+      const double* dg = hd.data() + offDg[a];
+      const double tau = std::max(atol, rtol * dg[0]);
+      int r = 0;
+      for (int j = 0; j < J.k; ++j)
+        if (dg[j] > tau) r = j + 1;
+      const int kmax = std::min(J.rows, J.cols);
+      if (r + 8 > J.k && J.k < kmax) {
+        J.k = std::min(2 * J.k, kmax);
+        next.push_back(todo[a]);
+        (void)hipFree(Y[a]);
+        Y[a] = nullptr;
+        hn[a].mcols[1] = 0;  // takes no part in the second phase of this pass
+        hn[a].mrows[1] = 0;
+        rank[a] = -1;
+      } else {
+        rank[a] = r;
+        any_done = true;
+      }
+    }
+    if (any_done) {
+      // ---- Z = L11^-1 * (P*X)[:k, :] on X itself for the finished blocks, then keep the first r rows ---------------
+      e = hipMemcpyAsync(dn, hn.data(), sizeof(NodeDesc<T>) * nj, hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) {
+        free_Y();
+        hs_set_error(-6, 0, "upload of the compression descriptors failed: %s", hipGetErrorString(e));
+        return -6;
+      }
+      sch.laswp(HS_MAT_UR, 0, HS_BIG, 0, P2);
+      sch.trsm_rec(HS_MAT_UR, 0, P2, 0, HS_BIG);
+      for (int a = 0; a < nj; ++a) {
+        if (rank[a] < 0) continue;
+        LowRankJob<T>& J = jobs[todo[a]];
+        LowRank<T>& o = *J.out;
+        const int r = rank[a];
+        o.ldz = std::max(2, (r + 1) / 2 * 2);
+        if (hipMalloc((void**)&o.Z, sizeof(T) * ((size_t)o.ldz * J.cols + 32)) != hipSuccess ||
+            hipMalloc((void**)&o.rperm, sizeof(int) * J.rows) != hipSuccess) {
+          free_Y();
+          hs_set_error(-7, 0, "hipMalloc of a low-rank factor (%d x %d) failed", r, J.cols);
+          return -7;
+        }
+        if (r > 0) hipLaunchKernelGGL(copy_top_rows_kernel<T>, dim3(J.cols), dim3(256), 0, s, (const T*)J.X, J.ldx, o.Z, o.ldz, r);
+        (void)hipMemcpyAsync(o.rperm, hn[a].rperm, sizeof(int) * J.rows, hipMemcpyDeviceToDevice, s);
+        o.Lp = Y[a];
+        Y[a] = nullptr;
+        o.ldp = ldp[a];
+        o.k = J.k;
+        o.r = r;
+      }
+    }
+    LRB_HIP(hipStreamSynchronize(s));  // the temporaries of this pass are released by `g`
+    todo.swap(next);
+  }
+  return 0;
+}
+
+template int lowrank_compress_batch<double>(LowRankJob<double>*, int, double, double, hipStream_t);
+template int lowrank_compress_batch<cplx>(LowRankJob<cplx>*, int, double, double, hipStream_t);

@@ -168,6 +168,26 @@ struct Sched {
       trsm_rec(mat, mid, r1, c0, c1);
     }
   }
+  // X[r0:r1, c0:c1) <- U[r0:r1, r0:r1]^-1 X  (upper factor of the interior block; backward block substitution)
+  void utrsm_rec(int mat, int r0, int r1, int c0, int c1) {
+    if (r0 >= maxni) return;
+    int nc = std::min(c1, cols_of(mat)) - c0;
+    if (nc <= 0) return;
+    if (r1 - r0 == HS_PB) {
+      GemmOp op{mat, mat, r0, r0 + HS_PB, c0, c1, 0, 0, 2};
+      hipEvent_t e0 = pf->begin(s);
+      launch_gemm_op<T>(dn, nbatch, HS_PB, nc, op, s);
+      pf->end(e0, HS_CAT_TRSM, s);
+      dbg("utrsm_blk", mat, r0, c0, c1);
+      return;
+    }
+    int mid = (r0 + r1) / 2;
+    if (mid < maxni) {
+      utrsm_rec(mat, mid, r1, c0, c1);
+      gemm(mat, mat, r0, mid, c0, c1, mid, r1);
+    }
+    utrsm_rec(mat, r0, mid, c0, c1);
+  }
   void lu_rec(int c0, int c1) {
     if (c0 >= maxni) return;
     if (c1 - c0 == HS_PB) {

@@ -65,7 +65,7 @@ __device__ inline bool resolve_op(const NodeDesc<T>* pn, const GemmOp& op, GemmP
     const int w = min(HS_PB, ni - op.r0);
     const int N = min(op.c1, ccols) - op.c0;
     if (w <= 0 || N <= 0) return false;
-    p.A = pn->invL + (size_t)(op.r0 / HS_PB) * HS_PB * HS_PB;
+    p.A = (op.ainv == 2 ? pn->invU : pn->invL) + (size_t)(op.r0 / HS_PB) * HS_PB * HS_PB;  // 2: inverse of the UPPER diagonal block
     p.B = cp + (size_t)op.r0 + (size_t)op.c0 * ldc;
     p.C = cp + (size_t)op.r0 + (size_t)op.c0 * ldc;
     p.M = w; p.N = N; p.K = w;
