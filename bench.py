@@ -112,7 +112,10 @@ def main():
     is_c = np.iscomplexobj(Ap.data)
 
     fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol) if args.swlevel != 0 else dict(swlevel=0)
+    t0 = time.perf_counter()
     S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, **fopts)
+    torch.cuda.synchronize(dev)
+    t_analyze = time.perf_counter() - t0  # hs_analyze: pattern upload, descriptors, hipMalloc of the factor arena (once per pattern)
     b_dev0 = torch.from_numpy(np.ascontiguousarray(bp)).to(dev)
     b_dev = torch.empty_like(b_dev0)
 
@@ -201,6 +204,7 @@ def main():
             "residual": res,
             "maxrank": int(S.backend.L.hs_maxrank(S.backend._h)) if getattr(S.backend, "_h", None) else None,
             "host_symbolic_s": t_host,
+            "analyze_s": t_analyze,
         }
         if flops:
             out["factor_tflops_minimal_count"] = flops / st["t_total"] / 1e12

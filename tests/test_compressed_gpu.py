@@ -107,3 +107,23 @@ def test_compressed_refactor_and_multirhs(hs):
     assert relerr(X, Xr) < 1e-5
     for j in range(3):
         assert relerr(hs.ldiv(F, B[:, j]), X[:, j]) < 1e-12
+
+
+def test_refactor_reuses_ranks_and_kest(hs):
+    """A second numeric factorization of the same handle starts its sketches from the ranks of the first one; `kest`
+    seeds the very first sketch (factorization.jl:102-104 uses kest the same way for the Schur sampling)."""
+    import torch
+
+    P = prepare(hs, (16, 16, 16), kind="poisson", nmax=64, rhs="randn")
+    xr = spla.splu(P["A"]).solve(P["b"])
+    S = hs.dist.StagedSolver(P["A"], P["nd"], P["nd_loc"], device=torch.device("cuda:0"), swlevel=-2, swsize=8, atol=1e-8, rtol=1e-8, kest=32)
+    errs, ranks = [], []
+    for _ in range(3):
+        S.numeric()
+        b = torch.from_numpy(np.ascontiguousarray(P["b"])).to("cuda:0")
+        S.solve(b)
+        errs.append(relerr(b.cpu().numpy(), xr))
+        ranks.append(int(S.backend.L.hs_maxrank(S.backend._h)))
+    assert max(errs) < 1e-5, errs
+    assert ranks[0] > 32  # the sketch had to grow beyond kest
+    assert max(ranks) - min(ranks) <= 8, ranks  # the randomized rank decision is stable between passes
