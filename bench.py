@@ -159,8 +159,11 @@ def main():
         S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, profile=True, **fopts)
         S.numeric()
         sp_ = S.stats()
-        if sp_["t_gemm"] > 0:
-            ach = sp_["gemm_flops"] / sp_["t_gemm"] / 1e12
+        if sp_["t_mfma_kernel"] > 0:
+            # every launch of the kernel `gemm_op_kernel` (trailing and Schur updates; the 32-row TRSM base cases run the same
+            # tile code under the name trsm_inv_kernel): `launches` and `avg_launch_ms` are what rocprofv3 --stats shows for it
+            t_k, n_k = sp_["t_mfma_kernel"], int(sp_["mfma_kernel_launches"])
+            ach = sp_["gemm_flops"] / t_k / 1e12
             roofline = {
                 "bound": "mfma",
                 "kernel": "gemm_op_kernel<%s> (v_mfma_f64_16x16x4_f64)" % ("cplx" if is_c else "double"),
@@ -169,14 +172,23 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_DATASHEET,
                 "traffic": None,
-                "launches": int(sp_["gemm_launches"]),
-                "avg_launch_ms": sp_["t_gemm"] * 1e3 / max(int(sp_["gemm_launches"]), 1),
-                "kernel_time_s": sp_["t_gemm"],
+                "launches": n_k,
+                "avg_launch_ms": t_k * 1e3 / max(n_k, 1),
+                "kernel_time_s": t_k,
                 "kernel_flops": sp_["gemm_flops"],
-                "share_of_factor_time": sp_["t_gemm"] / max(sp_["t_total"], 1e-30),
-                "phases_s": {"gemm": sp_["t_gemm"], "panel": sp_["t_panel"], "laswp+trsm": sp_["t_trsm"], "assemble": sp_["t_assemble"],
+                "flops_per_launch": sp_["gemm_flops"] / max(n_k, 1),
+                "share_of_factor_time": t_k / max(sp_["t_total"], 1e-30),
+                "phases_s": {"gemm_updates": sp_["t_gemm"], "panel": sp_["t_panel"], "laswp+trsm": sp_["t_trsm"], "assemble": sp_["t_assemble"],
                              "factor_total_profiled": sp_["t_total"]},
             }
+            # HBM bytes per launch from the committed PMC passes of the same workload (tools/pmc_bench.sh; counters
+            # cannot be read from inside the process)
+            pmc = os.path.join(ROOT, "profiles", "r01_%s_gemm_pmc_traffic.json" % args.workload)
+            if world == 1 and args.swlevel == 0 and os.path.exists(pmc):
+                with open(pmc) as f:
+                    pj = json.load(f)
+                roofline["traffic"] = pj["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 for gfx950)"
             peak_meas = S.backend.L.hsk_mfma_f64_peak(2, 100000)
             roofline["peak_measured_issue_rate"] = peak_meas
             roofline["frac_of_measured"] = ach / peak_meas if peak_meas > 0 else None

@@ -42,6 +42,7 @@ class hs_stats(C.Structure):
         ("t_symbolic", C.c_double), ("t_upload", C.c_double), ("t_assemble", C.c_double), ("t_panel", C.c_double),
         ("t_trsm", C.c_double), ("t_gemm", C.c_double), ("t_total", C.c_double), ("t_solve", C.c_double),
         ("gemm_flops", C.c_double), ("gemm_launches", i64),
+        ("t_mfma_kernel", C.c_double), ("mfma_kernel_launches", i64),
     ]
 
 

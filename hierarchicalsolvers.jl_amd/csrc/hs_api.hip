@@ -725,6 +725,8 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     if (L.mine.empty()) continue;
     const NodeDesc<T>* dn = dn_all + L.desc_off;
     const int nb_ = (int)L.mine.size();
+    static const bool progress = getenv("HS_PROGRESS") != nullptr;  // one line per level as it is enqueued (long profiler runs)
+    if (progress) fprintf(stderr, "[hs] enqueue level %d (%d fronts)\n", lv, nb_);
     hipEvent_t ea = h->prof.begin(s);
     // zero-fill this level's fronts: LF/UR are contiguous per level; SB of the owned fronts only
     // (a ghost child's SB holds received data and must survive)
@@ -790,6 +792,8 @@ static void numeric_end(hs_handle* h) {
     if (prev != h->ev0) (void)hipEventDestroy(prev);
     h->level_events.clear();
   }
+  h->stats.t_mfma_kernel = prof.ms[HS_CAT_GEMM] * 1e-3;  // gemm_op_kernel only: the TRSM base cases run as trsm_inv_kernel
+  h->stats.mfma_kernel_launches = prof.launches[HS_CAT_GEMM];
   h->stats.t_gemm = prof.ms[HS_CAT_GEMM] * 1e-3;
   h->stats.t_panel = prof.ms[HS_CAT_PANEL] * 1e-3;
   h->stats.t_trsm = (prof.ms[HS_CAT_TRSM] + prof.ms[HS_CAT_LASWP]) * 1e-3;

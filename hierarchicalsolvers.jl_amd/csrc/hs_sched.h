@@ -239,9 +239,15 @@ struct Sched {
     } else {
       mn.lu_rec(0, NB);
     }
-    for (int c0 = 0; c0 < maxni; c0 += NB) {
+    // the host may run at most 3 block columns (a few thousand launches) ahead of the device: an unbounded run-ahead
+    // filled the queues of a 32,768 front and crashed rocprofv3's queue interception
+    hipEvent_t ev_iter[3];
+    for (auto& e : ev_iter) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    int iter = 0;
+    for (int c0 = 0; c0 < maxni; c0 += NB, ++iter) {
       const int c1 = c0 + NB, c2 = c1 + NB;
       const bool has_next = c1 < maxni;
+      if (iter >= 3) (void)hipEventSynchronize(ev_iter[iter % 3]);
       if (has_next) {
         mn.laswp(HS_MAT_LF, c1, c2, c0, c1);
         mn.trsm_rec(HS_MAT_LF, c0, c1, c1, c2);
@@ -260,7 +266,9 @@ struct Sched {
         mn.gemm(HS_MAT_UR, HS_MAT_UR, c1, HS_BIG, 0, HS_BIG, c0, c1);
       }
       if (has_next) (void)hipStreamWaitEvent(mn.s, ev_side, 0);
+      (void)hipEventRecord(ev_iter[iter % 3], mn.s);
     }
+    for (auto& e : ev_iter) (void)hipEventDestroy(e);
     for (int c0 = 0; c0 + NB < maxni; c0 += NB) mn.laswp(HS_MAT_LF, c0, c0 + NB, c0 + NB, HS_BIG);
     if (s_la) {  // hand back to the handle's stream: the Schur update may use every CU again
       (void)hipEventRecord(ev_main, s_la);

@@ -434,7 +434,16 @@ __global__ __launch_bounds__(256, 2) void gemm_op_kernel(const NodeDesc<T>* __re
   extern __shared__ __attribute__((aligned(16))) double smem[];
   GemmProb<T> p;
   if (!resolve_op(nodes + blockIdx.y, op, p)) return;
-  gemm_dispatch<T>(p, op.ainv == 0, smem);
+  gemm_dispatch<T>(p, true, smem);
+}
+// The TRSM base case (X <- inv(diagonal block) * X, in place) runs the same tile code under its own name, so that
+// profiles separate the trailing updates (gemm_op_kernel: the flops) from the 32-row solves (latency).
+template <class T>
+__global__ __launch_bounds__(256, 2) void trsm_inv_kernel(const NodeDesc<T>* __restrict__ nodes, GemmOp op) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  GemmProb<T> p;
+  if (!resolve_op(nodes + blockIdx.y, op, p)) return;
+  gemm_dispatch<T>(p, false, smem);
 }
 
 template <class T>
@@ -492,9 +501,13 @@ void launch_gemm_op(const NodeDesc<T>* dnodes, int nbatch, int maxM, int maxN, c
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KiB of LDS per workgroup needs the opt-in
     (void)hipFuncSetAttribute((const void*)gemm_op_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)trsm_inv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_op_kernel<T>, dim3(tiles, nbatch), dim3(256), lds_bytes, s, dnodes, op);
+  if (op.ainv)
+    hipLaunchKernelGGL(trsm_inv_kernel<T>, dim3(tiles, nbatch), dim3(256), lds_bytes, s, dnodes, op);
+  else
+    hipLaunchKernelGGL(gemm_op_kernel<T>, dim3(tiles, nbatch), dim3(256), lds_bytes, s, dnodes, op);
 }
 static void set_stagger_once() {
   static bool done = false;

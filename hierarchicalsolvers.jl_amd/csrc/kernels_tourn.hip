@@ -44,7 +44,7 @@ void hs_create_lookahead_streams(hipStream_t* la, hipStream_t* side_masked, hipS
     (void)hipGetLastError();
   }
   const char* e = getenv("HS_LA_SIDE_CUS");
-  int ncu = e ? atoi(e) : 32;
+  int ncu = e ? atoi(e) : 0;  // opt-in: 32 reserved CUs took 7 % off a lone 32,768 front, but rocprofv3 crashed on CU-masked queues
   hipDeviceProp_t prop;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;

@@ -160,6 +160,10 @@ typedef struct hs_stats {
   double t_solve;        /* seconds, device time of last hs_ldiv */
   double gemm_flops;     /* flops executed by the MFMA GEMM kernel in the last hs_factor */
   int64_t gemm_launches;
+  /* every launch of the kernel `gemm_op_kernel` in the last hs_factor (the trailing/Schur updates; the 32-row TRSM base
+   * cases run the same tile code as `trsm_inv_kernel`): what a rocprofv3 --stats line of that kernel is compared with */
+  double t_mfma_kernel;
+  int64_t mfma_kernel_launches;
 } hs_stats;
 int hs_get_stats(const hs_handle* F, hs_stats* out);
 
