@@ -233,6 +233,43 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
   // ONE wave does the 32 dependent steps with the rows in registers (lane i = row i; the pivot row comes
   // from lane k through v_readlane, k a compile-time constant): no barriers, no LDS traffic inside the
   // chain -- the 128 workgroup barriers of the previous LDS formulation were 2/3 of this kernel's time.
+  if constexpr (sizeof(T) == 16) {
+    // ComplexF64: the register formulation needs 4x the instructions (270 KB of straight-line code, slower than
+    // the barrier chain it replaces) -- keep the LDS formulation: 256 threads, two barriers per step
+    for (int k = 0; k < HS_PB; ++k) {
+      const T piv = s_a[k][k];
+      const bool zero_piv = (Scal<T>::abs1(piv) == 0.0);
+      if (t < HS_PB && t > k && !zero_piv) s_a[t][k] = s_a[t][k] / piv;
+      if (zero_piv && t == 0 && k < w) {
+        int old = *nd.info;
+        if (old == 0 || old > c0 + k + 1) *nd.info = c0 + k + 1;
+      }
+      __syncthreads();
+      if (!zero_piv) {
+        for (int e = t; e < HS_PB * HS_PB; e += 256) {
+          int i = e & 31, j = e >> 5;
+          if (i > k) {
+            if (j > k)
+              s_a[i][j] = Scal<T>::fnma(s_a[i][k], s_a[k][j], s_a[i][j]);
+            else
+              s_il[i][j] = Scal<T>::fnma(s_a[i][k], s_il[k][j], s_il[i][j]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int p = HS_PB - 1; p >= 0; --p) {
+      T d = s_a[p][p];
+      if (Scal<T>::abs1(d) == 0.0) d = Scal<T>::one();
+      if (t < HS_PB && t >= p) s_iu[p][t] = s_iu[p][t] / d;
+      __syncthreads();
+      for (int e = t; e < HS_PB * HS_PB; e += 256) {
+        int i = e & 31, j = e >> 5;
+        if (i < p && j >= p) s_iu[i][j] = Scal<T>::fnma(s_a[i][p], s_iu[p][j], s_iu[i][j]);
+      }
+      __syncthreads();
+    }
+  } else
   if (t < 64) {
     const int i = t & 31;
     T ar[HS_PB], il[HS_PB];
