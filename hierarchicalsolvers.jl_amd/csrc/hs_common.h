@@ -143,9 +143,9 @@ int hs_tour_block_rows(bool is_complex);
 // Any of them may come back null (the schedule then falls back: no reservation / no look-ahead).
 void hs_create_lookahead_streams(hipStream_t* la, hipStream_t* side_masked, hipStream_t* side);  // rows one workgroup of a tournament stage reduces to 32 nominees
 template <class T>
-void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, hipStream_t s);
+void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, int fuse, hipStream_t s);
 template <class T>
-void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, hipStream_t s);
+void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, int fuse, hipStream_t s);
 template <class T>
 void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1, int k0, int k1, int maxcols, hipStream_t s);
 template <class T>

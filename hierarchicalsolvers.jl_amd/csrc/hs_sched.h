@@ -21,6 +21,8 @@ struct Profiler {
   struct Rec {
     hipEvent_t e0, e1;
     int cat;
+    double fl;
+    int M, N, K, nbatch;
   };
   std::vector<Rec> recs;
   double flops[HS_NCAT] = {0, 0, 0, 0, 0};
@@ -34,22 +36,26 @@ struct Profiler {
     }
     return e;
   }
-  void end(hipEvent_t e0, int cat, hipStream_t s, double fl = 0.0) {
+  void end(hipEvent_t e0, int cat, hipStream_t s, double fl = 0.0, int M = 0, int N = 0, int K = 0, int nbatch = 0) {
     launches[cat]++;
     flops[cat] += fl;
     if (!on) return;
     hipEvent_t e1;
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e1, s);
-    recs.push_back({e0, e1, cat});
+    recs.push_back({e0, e1, cat, fl, M, N, K, nbatch});
   }
   void collect() {  // call after the stream has been synchronised
+    const char* logf = getenv("HS_GEMM_LOG");  // diagnostics: one line per GEMM launch (max M, N, K of the batch, flops, ms)
+    FILE* lf = (logf && on) ? fopen(logf, "a") : nullptr;
     for (auto& r : recs) {
       float t = 0.f;
       if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) ms[r.cat] += t;
+      if (lf && r.cat == HS_CAT_GEMM) fprintf(lf, "%d %d %d %d %.6g %.6f\n", r.M, r.N, r.K, r.nbatch, r.fl, t);
       (void)hipEventDestroy(r.e0);
       (void)hipEventDestroy(r.e1);
     }
+    if (lf) fclose(lf);
     recs.clear();
   }
 };
@@ -103,10 +109,10 @@ struct Sched {
     }
     hipEvent_t e0 = pf->begin(s);
     launch_gemm_op<T>(dn, nbatch, M, N, op, s);
-    pf->end(e0, HS_CAT_GEMM, s, fl);
+    pf->end(e0, HS_CAT_GEMM, s, fl, M, N, K, nbatch);
     dbg("gemm", cmat, r0, c0, k0);
   }
-  void panel(int pb) {
+  void panel(int pb, int fuse = 0) {
     int c0 = pb * HS_PB;
     if (c0 >= maxni) return;
     // pivot search: 256-row chunks (4 waves, modest registers: finds a slot next to a running GEMM) by default;
@@ -133,9 +139,9 @@ struct Sched {
         nch = (cnt + HS_CHUNK - 1) / HS_CHUNK;
       }
     }
-    launch_panel_pivot<T>(dn, nbatch, pb, s);
+    launch_panel_pivot<T>(dn, nbatch, pb, fuse, s);
     dbg("panel_pivot", pb);
-    launch_panel_l21<T>(dn, nbatch, pb, maxm - c0, s);
+    launch_panel_l21<T>(dn, nbatch, pb, maxm - c0, fuse, s);
     dbg("panel_l21", pb);
     pf->end(e0, HS_CAT_PANEL, s);
   }
@@ -192,6 +198,14 @@ struct Sched {
     if (c0 >= maxni) return;
     if (c1 - c0 == HS_PB) {
       panel(c0 / HS_PB);
+      return;
+    }
+    static const int pair = env_int("HS_PANEL_PAIR", 1);
+    if (pair && c1 - c0 == 2 * HS_PB) {
+      // 64-column pair: the first panel's kernels also swap, solve and update the second panel's columns, the second
+      // panel's pivot kernel also swaps the first panel's columns -- 6 launches instead of 10, no sub-tile GEMM
+      panel(c0 / HS_PB, 1);
+      if (c0 + HS_PB < maxni) panel(c0 / HS_PB + 1, 2);
       return;
     }
     int mid = (c0 + c1) / 2;

@@ -137,12 +137,16 @@ __global__ __launch_bounds__(HS_CHUNK) void tournament_kernel(const NodeDesc<T>*
 // panel_pivot: one workgroup per front.
 // ------------------------------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __restrict__ nodes, int pb) {
+__global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int fuse) {
   const NodeDesc<T> nd = nodes[blockIdx.y];
   const int c0 = pb * HS_PB;
   if (c0 >= nd.ni) return;
   const int w = min(HS_PB, nd.ni - c0);
   const int t = threadIdx.x;
+  // fuse & 1: first panel of a 64-column pair -- also swap the NEXT 32 columns and leave U12 = inv(L11)*A12 in them
+  //           (panel_l21 then applies the rank-32 update to those columns): no laswp / TRSM / GEMM launches in the pair
+  // fuse & 2: second panel of the pair -- also swap the PREVIOUS 32 columns (the left-looking swap of the pair)
+  const int w2 = (fuse & 1) ? max(0, min(HS_PB, nd.ni - (c0 + HS_PB))) : 0;
 
   __shared__ int s_piv[HS_PB];     // swap target of row c0+k
   __shared__ int s_where[HS_PB];   // current position of the row that started at top position c0+i
@@ -193,8 +197,7 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
   // "column", to the accumulated row permutation -- as ONE gather/scatter of the <= 2w touched rows
   // (top position k receives the row s_what[k]; the row that started at top position i goes to
   // s_where[i]), so all loads are independent instead of 2w dependent global round trips.
-  if (t < w) {
-    T* col = nd.LF + (size_t)(c0 + t) * nd.ldl;
+  auto swap_column = [&](T* col) {
     T topv[HS_PB], pivv[HS_PB];
 #pragma unroll
     for (int i = 0; i < HS_PB; ++i) {
@@ -209,6 +212,13 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
         if (f < c0 || f >= c0 + w) col[f] = topv[i];
       }
     }
+  };
+  if (t < w) {
+    swap_column(nd.LF + (size_t)(c0 + t) * nd.ldl);
+  } else if (t >= 128 && t < 128 + w2) {
+    swap_column(nd.LF + (size_t)(c0 + HS_PB + (t - 128)) * nd.ldl);
+  } else if ((fuse & 2) && t >= 192 && t < 192 + HS_PB && c0 >= HS_PB) {
+    swap_column(nd.LF + (size_t)(c0 - HS_PB + (t - 192)) * nd.ldl);
   } else if (t >= 64 && t < 64 + w) {
     const int i = t - 64;
     const int topv = nd.rperm[c0 + i], pivv = nd.rperm[s_what[i]];
@@ -342,21 +352,49 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
     nd.invL[(size_t)pb * HS_PB * HS_PB + e] = s_il[i][j];
     nd.invU[(size_t)pb * HS_PB * HS_PB + e] = s_iu[i][j];
   }
+  if (w2 > 0) {  // U12 = inv(L11) * (P*A)[c0:c0+w, next 32 columns], in place
+    __syncthreads();
+    for (int e = t; e < HS_PB * HS_PB; e += 256) {
+      int i = e & 31, j = e >> 5;
+      T v = Scal<T>::zero();
+      if (i < w && j < w2) v = nd.LF[(size_t)(c0 + i) + (size_t)(c0 + HS_PB + j) * nd.ldl];
+      s_a[i][j] = v;
+    }
+    __syncthreads();
+    for (int e = t; e < HS_PB * HS_PB; e += 256) {
+      int i = e & 31, j = e >> 5;
+      if (i < w && j < w2) {
+        T u = Scal<T>::zero();
+        for (int q = 0; q <= i; ++q) u = Scal<T>::fma(s_il[i][q], s_a[q][j], u);
+        nd.LF[(size_t)(c0 + i) + (size_t)(c0 + HS_PB + j) * nd.ldl] = u;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // panel_l21: rows below the diagonal block, one row per thread:  x <- x * inv(U11)
 // ------------------------------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __restrict__ nodes, int pb) {
+__global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int fuse) {
   const NodeDesc<T> nd = nodes[blockIdx.y];
   const int c0 = pb * HS_PB;
   if (c0 >= nd.ni) return;
   const int w = min(HS_PB, nd.ni - c0);
   const int r0 = c0 + w;
   if ((int)blockIdx.x * 256 >= nd.m - r0) return;
+  // fuse & 1: first panel of a 64-column pair -- the thread that owns a row also applies the rank-32 update
+  // A[row, next 32 columns] -= L21[row, :] * U12 (U12 left in place by panel_pivot), with L21[row, :] still in registers
+  const int w2 = (fuse & 1) ? max(0, min(HS_PB, nd.ni - (c0 + HS_PB))) : 0;
   __shared__ T s_iu[HS_PB * HS_PB];  // column-major, ld 32
-  for (int e = threadIdx.x; e < HS_PB * HS_PB; e += 256) s_iu[e] = nd.invU[(size_t)pb * HS_PB * HS_PB + e];
+  __shared__ T s_u[HS_PB * HS_PB];   // U12, column-major, ld 32
+  for (int e = threadIdx.x; e < HS_PB * HS_PB; e += 256) {
+    s_iu[e] = nd.invU[(size_t)pb * HS_PB * HS_PB + e];
+    if (w2 > 0) {
+      const int i = e & 31, j = e >> 5;
+      s_u[e] = (i < w && j < w2) ? nd.LF[(size_t)(c0 + i) + (size_t)(c0 + HS_PB + j) * nd.ldl] : Scal<T>::zero();
+    }
+  }
   __syncthreads();
   const int row = r0 + blockIdx.x * 256 + threadIdx.x;
   if (row >= nd.m) return;
@@ -364,14 +402,26 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
   T a[HS_PB];
 #pragma unroll
   for (int j = 0; j < HS_PB; ++j) a[j] = (j < w) ? base[(size_t)j * nd.ldl] : Scal<T>::zero();
+  T l[HS_PB];
 #pragma unroll
   for (int j = 0; j < HS_PB; ++j) {
-    if (j < w) {
-      T s = Scal<T>::zero();
+    T s = Scal<T>::zero();
 #pragma unroll
-      for (int i = 0; i < HS_PB; ++i)
-        if (i <= j) s = Scal<T>::fma(a[i], s_iu[i + j * HS_PB], s);
-      base[(size_t)j * nd.ldl] = s;
+    for (int i = 0; i < HS_PB; ++i)
+      if (i <= j) s = Scal<T>::fma(a[i], s_iu[i + j * HS_PB], s);
+    l[j] = s;
+    if (j < w) base[(size_t)j * nd.ldl] = s;
+  }
+  if (w2 > 0) {
+    T* nxt = base + (size_t)HS_PB * nd.ldl;
+#pragma unroll 4
+    for (int j = 0; j < HS_PB; ++j) {
+      if (j < w2) {
+        T v = nxt[(size_t)j * nd.ldl];
+#pragma unroll
+        for (int q = 0; q < HS_PB; ++q) v = Scal<T>::fnma(l[q], s_u[q + j * HS_PB], v);
+        nxt[(size_t)j * nd.ldl] = v;
+      }
     }
   }
 }
@@ -444,14 +494,14 @@ void launch_tournament_round(const NodeDesc<T>* dnodes, int nbatch, int pb, int 
   hipLaunchKernelGGL(tournament_kernel<T>, dim3(maxchunks, nbatch), dim3(HS_CHUNK), 0, s, dnodes, pb, round);
 }
 template <class T>
-void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, hipStream_t s) {
+void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, int fuse, hipStream_t s) {
   if (nbatch <= 0) return;
-  hipLaunchKernelGGL(panel_pivot_kernel<T>, dim3(1, nbatch), dim3(256), 0, s, dnodes, pb);
+  hipLaunchKernelGGL(panel_pivot_kernel<T>, dim3(1, nbatch), dim3(256), 0, s, dnodes, pb, fuse);
 }
 template <class T>
-void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, hipStream_t s) {
+void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, int fuse, hipStream_t s) {
   if (nbatch <= 0 || maxrows <= 0) return;
-  hipLaunchKernelGGL(panel_l21_kernel<T>, dim3((maxrows + 255) / 256, nbatch), dim3(256), 0, s, dnodes, pb);
+  hipLaunchKernelGGL(panel_l21_kernel<T>, dim3((maxrows + 255) / 256, nbatch), dim3(256), 0, s, dnodes, pb, fuse);
 }
 template <class T>
 void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1, int k0, int k1, int maxcols, hipStream_t s) {
@@ -466,8 +516,8 @@ void launch_trsm_blk(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int
 
 #define INST(T)                                                                                         \
   template void launch_tournament_round<T>(const NodeDesc<T>*, int, int, int, int, hipStream_t);        \
-  template void launch_panel_pivot<T>(const NodeDesc<T>*, int, int, hipStream_t);                       \
-  template void launch_panel_l21<T>(const NodeDesc<T>*, int, int, int, hipStream_t);                    \
+  template void launch_panel_pivot<T>(const NodeDesc<T>*, int, int, int, hipStream_t);                       \
+  template void launch_panel_l21<T>(const NodeDesc<T>*, int, int, int, int, hipStream_t);                    \
   template void launch_laswp<T>(const NodeDesc<T>*, int, int, int, int, int, int, int, hipStream_t);    \
   template void launch_trsm_blk<T>(const NodeDesc<T>*, int, int, int, int, int, int, hipStream_t);
 INST(double)
