@@ -93,8 +93,8 @@ struct Sched {
   int rows_of(int mat) const { return mat == HS_MAT_LF ? maxm : (mat == HS_MAT_UR ? maxni : maxnb); }
   int cols_of(int mat) const { return mat == HS_MAT_LF ? maxni : maxnb; }
 
-  void gemm(int cmat, int bmat, int r0, int r1, int c0, int c1, int k0, int k1) {
-    GemmOp op{cmat, bmat, r0, r1, c0, c1, k0, k1, 0};
+  void gemm(int cmat, int bmat, int r0, int r1, int c0, int c1, int k0, int k1, int cap = 0) {
+    GemmOp op{cmat, bmat, r0, r1, c0, c1, k0, k1, 0, cap};
     int M = std::min(r1, rows_of(cmat)) - r0, N = std::min(c1, cols_of(cmat)) - c0, K = std::min(k1, maxni) - k0;
     if (M <= 0 || N <= 0 || K <= 0) return;
     double fl = 0.0;
@@ -255,6 +255,11 @@ struct Sched {
     }
     // the host may run at most 3 block columns (a few thousand launches) ahead of the device: an unbounded run-ahead
     // filled the queues of a 32,768 front and crashed rocprofv3's queue interception
+    // the updates that run while the side stream factors the next panel leave workgroup slots free (every CU can hold
+    // two GEMM workgroups; HS_LA_GEMM_CAP of them in total, default 448 of the 512): the ~10 tiny dependent kernels of
+    // each 32-column panel step then start at once instead of waiting for a GEMM workgroup to retire
+    static const int cap_total = env_int("HS_LA_GEMM_CAP", 448);
+    const int gcap = (cap_total > 0 && nbatch == 1) ? cap_total : 0;  // measured: helps a lone front, hurts batches (uneven fronts)
     hipEvent_t ev_iter[3];
     for (auto& e : ev_iter) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     int iter = 0;
@@ -272,12 +277,12 @@ struct Sched {
         (void)hipEventRecord(ev_side, s2);
         mn.laswp(HS_MAT_LF, c2, HS_BIG, c0, c1);
         mn.trsm_rec(HS_MAT_LF, c0, c1, c2, HS_BIG);
-        mn.gemm(HS_MAT_LF, HS_MAT_LF, c1, HS_BIG, c2, HS_BIG, c0, c1);
+        mn.gemm(HS_MAT_LF, HS_MAT_LF, c1, HS_BIG, c2, HS_BIG, c0, c1, has_next ? gcap : 0);
       }
       if (maxnb > 0) {
         mn.laswp(HS_MAT_UR, 0, HS_BIG, c0, c1);
         mn.trsm_rec(HS_MAT_UR, c0, c1, 0, HS_BIG);
-        mn.gemm(HS_MAT_UR, HS_MAT_UR, c1, HS_BIG, 0, HS_BIG, c0, c1);
+        mn.gemm(HS_MAT_UR, HS_MAT_UR, c1, HS_BIG, 0, HS_BIG, c0, c1, has_next ? gcap : 0);
       }
       if (has_next) (void)hipStreamWaitEvent(mn.s, ev_side, 0);
       (void)hipEventRecord(ev_iter[iter % 3], mn.s);

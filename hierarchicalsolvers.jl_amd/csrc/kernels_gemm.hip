@@ -19,6 +19,7 @@
 //
 // Complex: planar split when staging (re / im images in LDS), 4 real MFMAs per k-step
 // (re += ar*br - ai*bi, im += ar*bi + ai*br); 128x64 tile, wave tile 64x32.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -419,14 +420,18 @@ __device__ inline void gemm_dispatch(const GemmProb<T>& p, bool minus, double* s
   }
   int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + TileCfg<T>::bn - 1) / TileCfg<T>::bn;
   int ntiles = tiles_m * tiles_n;
-  if ((int)blockIdx.x >= ntiles) return;
-  int t = xcd_remap(blockIdx.x, ntiles);
-  int tm, tn;
-  tile_coords(t, tiles_m, tiles_n, tm, tn);
-  if constexpr (sizeof(T) == 8)
-    gemm_tile_d<128>(p, tm, tn, minus, smem);
-  else
-    gemm_tile_z(p, tm, tn, minus, smem);
+  // a launch may be capped to fewer workgroups than tiles (GemmOp::cap): each workgroup then walks the tiles
+  // bid, bid + gridDim.x, ... -- with gridDim.x a multiple of 8 they all stay in the same XCD chunk of the remap
+  for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
+    int t = xcd_remap(bid, ntiles);
+    int tm, tn;
+    tile_coords(t, tiles_m, tiles_n, tm, tn);
+    if constexpr (sizeof(T) == 8)
+      gemm_tile_d<128>(p, tm, tn, minus, smem);
+    else
+      gemm_tile_z(p, tm, tn, minus, smem);
+    if (bid + (int)gridDim.x < ntiles) __syncthreads();  // the next tile re-uses the LDS stages
+  }
 }
 
 template <class T>
@@ -497,6 +502,7 @@ void launch_gemm_op(const NodeDesc<T>* dnodes, int nbatch, int maxM, int maxN, c
   }
   set_stagger_once();
   int tiles = ((maxM + BM - 1) / BM) * ((maxN + TileCfg<T>::bn - 1) / TileCfg<T>::bn);
+  if (op.cap > 0 && tiles > op.cap) tiles = std::max(8, op.cap / 8 * 8);
   constexpr int lds_bytes = TileCfg<T>::smem_doubles * 8;
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KiB of LDS per workgroup needs the opt-in
