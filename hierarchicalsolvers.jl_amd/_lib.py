@@ -59,6 +59,7 @@ EXPORTS = [
     "hs_analyze", "hs_plan", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned",
+    "hs_symbolic_from_elimtree", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak",
 ]
 
@@ -149,6 +150,16 @@ def lib():
     L.hs_get_stats.restype = C.c_int
     L.hs_node_info.argtypes = [vp, i64, p_i64, p_i64, p_i64]
     L.hs_node_info.restype = C.c_int
+    L.hs_symbolic_from_elimtree.argtypes = [i64, p_i64, p_i64, p_i64, p_i64, p_i64, i64, p_i64, p_i64, i64, C.POINTER(vp)]
+    L.hs_symbolic_from_elimtree.restype = C.c_int
+    L.hs_symbolic_size.argtypes = [vp]
+    L.hs_symbolic_size.restype = i64
+    L.hs_symbolic_perm.argtypes = [vp]
+    L.hs_symbolic_perm.restype = p_i64
+    L.hs_symbolic_tree.argtypes = [vp, C.POINTER(hs_tree)]
+    L.hs_symbolic_tree.restype = C.c_int
+    L.hs_symbolic_free.argtypes = [vp]
+    L.hs_symbolic_free.restype = None
     L.hs_node_ranks.argtypes = [vp, i64, p_i64, p_i64]
     L.hs_node_ranks.restype = C.c_int
     L.hs_node_export.argtypes = [vp, i64, C.c_int, p_f64]

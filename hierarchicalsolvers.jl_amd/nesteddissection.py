@@ -30,6 +30,7 @@ __all__ = [
     "getinterior",
     "getboundary",
     "flatten_tree",
+    "native_symbolic",
 ]
 
 
@@ -246,7 +247,10 @@ def flatten_tree(nd, nd_loc):
     """Flat post-ordered arrays for ``hs_tree`` (include/hs_solver.h).
 
     Node ids are 0-based post-order positions (root last, ``-1`` = no child);
-    DOF ids and local positions stay 1-based as Julia holds them."""
+    DOF ids and local positions stay 1-based as Julia holds them.  A dict that already is such a flat tree
+    (:func:`native_symbolic`) is passed through (``nd_loc`` is then ignored)."""
+    if isinstance(nd, dict) and "nnodes" in nd:
+        return nd
     nodes, locs = [], []
     stack = [(nd, nd_loc, False)]
     while stack:
@@ -280,3 +284,47 @@ def flatten_tree(nd, nd_loc):
         int_ptr=int_ptr, int_idx=int_idx, bnd_ptr=bnd_ptr, bnd_idx=bnd_idx,
         iloc_ptr=iloc_ptr, iloc_idx=iloc_idx, bloc_ptr=bloc_ptr, bloc_idx=bloc_idx,
     )
+
+
+def native_symbolic(fathers, lsons, rsons, ninter, inter, nbound, bound):
+    """The whole host pipeline of the reference's scenario (``parse_elimtree`` -> ``symfact!`` -> ``postorder`` ->
+    ``permuted!(nd, invperm(perm))``, test/rungmres.jl:15-19) in the C++ symbolic layer (``include/hs_symbolic.h``).
+
+    Returns ``(tree, perm)``: ``tree`` is the flat post-ordered tree in the permuted numbering -- pass it as ``nd``
+    (with ``nd_loc=None``) to :func:`factor` / ``StagedSolver`` -- and ``perm`` (1-based) is the elimination order:
+    factor ``A[perm-1][:, perm-1]``.  No GPU needed."""
+    import ctypes as C
+
+    from . import _lib
+
+    fathers, lsons, rsons, ninter, nbound = (_ivec(a) for a in (fathers, lsons, rsons, ninter, nbound))
+    inter = np.asfortranarray(np.asarray(inter, dtype=np.int64))
+    bound = np.asfortranarray(np.asarray(bound, dtype=np.int64))
+    inter = inter.reshape(inter.shape[0], -1, order="F") if inter.ndim == 2 else inter.reshape(-1, 1, order="F")
+    bound = bound.reshape(bound.shape[0], -1, order="F") if bound.ndim == 2 else bound.reshape(-1, 1, order="F")
+    nn = len(fathers)
+    if not (nn == len(lsons) == len(rsons) == len(ninter) == len(nbound) == inter.shape[1] == bound.shape[1]):
+        raise _lib.DimensionMismatch("DimensionMismatch: dimensions inconsistent among inputs")
+    L = _lib.lib()
+    h = C.c_void_p()
+    p = lambda a: a.ctypes.data_as(_lib.p_i64)  # noqa: E731
+    _lib.check(L.hs_symbolic_from_elimtree(nn, p(fathers), p(lsons), p(rsons), p(ninter), p(inter), inter.shape[0], p(nbound), p(bound),
+                                           bound.shape[0], C.byref(h)))
+    try:
+        n = int(L.hs_symbolic_size(h))
+        perm = np.ctypeslib.as_array(L.hs_symbolic_perm(h), shape=(n,)).copy() if n else np.zeros(0, np.int64)
+        t = _lib.hs_tree()
+        _lib.check(L.hs_symbolic_tree(h, C.byref(t)))
+        k = int(t.nnodes)
+
+        def arr(ptr, m):
+            return np.ctypeslib.as_array(ptr, shape=(m,)).copy() if m else np.zeros(0, np.int64)
+
+        tree = dict(nnodes=k, left=arr(t.left, k), right=arr(t.right, k))
+        for name in ("int", "bnd", "iloc", "bloc"):
+            ptr = arr(getattr(t, name + "_ptr"), k + 1)
+            tree[name + "_ptr"] = ptr
+            tree[name + "_idx"] = arr(getattr(t, name + "_idx"), int(ptr[-1]))
+    finally:
+        L.hs_symbolic_free(h)
+    return tree, perm

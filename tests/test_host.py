@@ -96,7 +96,7 @@ def test_options_mirror(hs):
 def test_library_exports_every_declared_symbol(hs):
     lib = hs._lib.lib()
     declared = set()
-    for hdr in ("hs_solver.h", "hs_kernels.h"):
+    for hdr in ("hs_solver.h", "hs_kernels.h", "hs_symbolic.h"):
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         declared |= set(re.findall(r"\b(hsk?_[a-z0-9_]+)\s*\(", txt))
@@ -126,3 +126,52 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(txt), f
+
+
+@pytest.mark.parametrize("name,kw", [("poisson2d_p1_h64_nmax100", {}), ((12, 10, 9), dict(kind="helmholtz", nmax=40)), ((33, 17), dict(kind="poisson", nmax=25))])
+def test_native_symbolic_layer_matches_the_python_mirror(name, kw):
+    """C++ parse_elimtree -> symfact! -> postorder -> permuted! (include/hs_symbolic.h) == the Python mirror == the oracle."""
+    import hsamd
+
+    hs = hsamd.load()
+    A, b, nd = hs.problems.make_problem(name, **kw)
+    arrays = hs.serialize_elimtree(nd)
+    tree, perm = hs.native_symbolic(*arrays)
+    nd2, nd_loc = hs.symfact(hs.parse_elimtree(*arrays))
+    perm_py = hs.postorder(nd2)
+    nd2 = hs.permuted(nd2, hs.invperm(perm_py))
+    flat = hs.flatten_tree(nd2, nd_loc)
+    assert np.array_equal(perm, perm_py)
+    assert tree["nnodes"] == flat["nnodes"]
+    for k in ("left", "right", "int_ptr", "int_idx", "bnd_ptr", "bnd_idx", "iloc_ptr", "iloc_idx", "bloc_ptr", "bloc_idx"):
+        assert np.array_equal(tree[k], flat[k]), k
+    from oracle import hs_oracle as O
+
+    o = O.parse_elimtree(*arrays)
+    o, _ = O.symfact(o)
+    assert np.array_equal(O.postorder(o), perm)
+    # the flat tree is accepted wherever (nd, nd_loc) is: host-only plan
+    h = hs.dist.plan_only(A[perm - 1][:, perm - 1].tocsc(), tree, None)
+    assert hs._lib.lib().hs_nlevels(h) == hs.depth(nd2)
+    hs._lib.lib().hs_free(h)
+
+
+def test_native_symbolic_layer_errors():
+    import hsamd
+
+    hs = hsamd.load()
+    A, b, nd = hs.problems.make_problem((9, 9), kind="poisson", nmax=10)
+    f, ls, rs, ni, inter, nb, bound = [np.array(a, copy=True) for a in hs.serialize_elimtree(nd)]
+    f2 = f.copy()
+    f2[0] = -1  # two roots
+    with pytest.raises(ValueError):
+        hs.native_symbolic(f2, ls, rs, ni, inter, nb, bound)
+    # a branch DOF that no child carries: silently dropped by the reference (nesteddissection.jl:63), an error here
+    root = int(np.nonzero(f == -1)[0][0])
+    inter2 = np.vstack([inter, np.zeros((1, inter.shape[1]), np.int64)])
+    ni2 = ni.copy()
+    leaf = int(np.nonzero(ls == -1)[0][0])
+    inter2[ni2[root], root] = inter[0, leaf]  # an interior DOF of a leaf claimed by the root as well
+    ni2[root] += 1
+    with pytest.raises(hs.DimensionMismatch):
+        hs.native_symbolic(f, ls, rs, ni2, inter2, nb, bound)
