@@ -120,6 +120,9 @@ struct NodeH {
   void* lrL = nullptr;      // LowRank<T>* of Lbi = Abi*U^-1  (nb x ni)
   void* lrR = nullptr;      // LowRank<T>* of Uib = L^-1*P*Aib (ni x nb)
   int last_rL = 0, last_rR = 0;  // ranks found by the previous factorization (initial sketch width of the next one)
+  int kind = 0;                  // hs_split.h: 0 ordinary, 1 first slice of a split front, 2 later slice
+  int user = -1;                 // user (post-order) node id this internal node belongs to
+  int oni = 0, oni1 = 0, onb1 = 0;  // split points of the front the children address (= ni, ni1, nb1 unless kind 1)
 };
 
 struct LevelH {
@@ -141,12 +144,15 @@ struct Exchange {
 };
 
 #include "hs_sched.h"
+#include "hs_split.h"
 
 struct hs_handle {
   bool is_complex = false;
   int64_t n = 0, nnz = 0;
   int nnodes = 0;  // tree nodes (+1 pseudo-node when the root keeps a boundary)
-  int nreal = 0;
+  int nreal = 0;   // internal nodes without the pseudo-root (= user nodes unless fronts are split, hs_split.h)
+  int nuser = 0;   // nodes of the user's tree
+  std::vector<int> last_of_user, first_of_user, u_ni, u_nb, u_level;  // only when fronts are split
   int rank = 0, nranks = 1, cut_level = 1;  // levels > cut_level are rank-local
   hs_options opts;
   std::vector<NodeH> nodes;
@@ -215,7 +221,7 @@ static void free_handle(hs_handle* h) {
 extern "C" void hs_free(hs_handle* h) { free_handle(h); }
 
 // Build and validate the node table from the flat 1-based tree (symfact! output).
-static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
+static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr, const SplitTree* st = nullptr) {
   if (!tr || tr->nnodes <= 0) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: empty tree");
   const int nn = (int)tr->nnodes;
   h->nreal = nn;
@@ -226,15 +232,17 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
     NodeH& x = N[i];
     x.left = (int)tr->left[i];
     x.right = (int)tr->right[i];
-    if ((x.left < 0) != (x.right < 0))
+    x.kind = st ? st->kind[i] : 0;
+    x.user = st ? st->user[i] : i;
+    if ((x.left < 0) != (x.right < 0) && x.kind != 2)  // a later slice of a split front has one child: the previous slice
       HS_FAIL(HS_ERR_TREE, i, "Expected nested dissection to be a binary tree. Found a node with only one child.");
     x.leaf = x.left < 0;
     if (!x.leaf) {
       if (x.left >= i || x.right >= i || x.left == x.right)
         HS_FAIL(HS_ERR_ARGUMENT, i, "ArgumentError: tree is not in post-order (children must precede node %d)", i);
-      if (N[x.left].parent >= 0 || N[x.right].parent >= 0) HS_FAIL(HS_ERR_ARGUMENT, i, "ArgumentError: node has two parents");
+      if (N[x.left].parent >= 0 || (x.right >= 0 && N[x.right].parent >= 0)) HS_FAIL(HS_ERR_ARGUMENT, i, "ArgumentError: node has two parents");
       N[x.left].parent = i;
-      N[x.right].parent = i;
+      if (x.right >= 0) N[x.right].parent = i;
     }
     x.ni = len(tr->int_ptr, i);
     x.nb = len(tr->bnd_ptr, i);
@@ -270,12 +278,23 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
     if (x.leaf) {
       x.ni1 = x.ni;
       x.nb1 = x.nb;
+      x.oni = x.ni; x.oni1 = x.ni1; x.onb1 = x.nb1;
+      continue;
+    }
+    if (x.kind == 1) {
+      // first slice of a split front (hs_split.h): the children address the ORIGINAL front [int; bnd] of the user's node,
+      // of which this node's [int; bnd] is the same sequence with the int/bnd border moved; the user's node was validated
+      // by the caller of make_split_tree through its last slice
+      x.oni = st->oni[i]; x.oni1 = st->oni1[i]; x.onb1 = st->onb1[i];
+      x.ni1 = x.ni;
+      x.nb1 = x.nb;
       continue;
     }
     // int = [left.bnd[iloc_left]; right.bnd[iloc_right]], bnd likewise (nesteddissection.jl:64-65, factorization.jl:63-64)
     int pi = 0, pb = 0;
     for (int side = 0; side < 2; ++side) {
       int c = side == 0 ? x.left : x.right;
+      if (c < 0) continue;
       const NodeH& ch = N[c];
       const int* cb = F.data() + ch.off_fidx + ch.ni;
       for (int64_t e = tr->iloc_ptr[c]; e < tr->iloc_ptr[c + 1]; ++e, ++pi) {
@@ -297,6 +316,7 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
     }
     if (pi != x.ni || pb != x.nb)
       HS_FAIL(HS_ERR_DIMENSION, i, "DimensionMismatch: children contribute (%d,%d) DOFs, node %d has (%d,%d)", pi, pb, i, x.ni, x.nb);
+    x.oni = x.ni; x.oni1 = x.ni1; x.onb1 = x.nb1;
   }
   // every DOF is eliminated at most once; the reference concatenates child Schur complements, it
   // never extend-adds (factorization.jl:118-121), so fronts of unrelated nodes are disjoint
@@ -321,6 +341,7 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
     r.m = r.ni;
     r.ni1 = r.ni;
     r.nb1 = 0;
+    r.oni = r.ni; r.oni1 = r.ni1; r.onb1 = 0;
     r.level = 0;
     r.off_fidx = F.size();
     for (int e = 0; e < root.nb; ++e) F.push_back(F[root.off_fidx + root.ni + e]);
@@ -347,7 +368,10 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr) {
       x.owner = lo[i];
       x.mine = (x.owner == h->rank);
       if (!x.leaf && x.level >= 1) {
-        if (cnt[i] > 1) {
+        if (x.right < 0) {  // later slice of a split front (single-rank plans only): same ranks as its only child
+          lo[x.left] = lo[i];
+          cnt[x.left] = cnt[i];
+        } else if (cnt[i] > 1) {
           lo[x.left] = lo[i];
           cnt[x.left] = cnt[i] / 2;
           lo[x.right] = lo[i] + cnt[i] / 2;
@@ -420,13 +444,31 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     h->rank = rank;
     h->nranks = nranks;
     memset(&h->stats, 0, sizeof h->stats);
-    build_plan(h, n, tree);
+    h->nuser = tree ? (int)tree->nnodes : 0;
+    SplitTree split;
+    make_split_tree(tree, opts, nranks, split);  // hs_split.h: large compressed fronts are eliminated in slices
+    if (split.active) {
+      build_plan(h, n, tree);  // validates the user's tree (same errors as without slices) ...
+      free_lowrank_any(h);
+      h->nodes.clear();
+      h->levels.clear();
+      h->exchanges.clear();
+      tree = &split.view;      // ... which is then replaced by the rewritten one
+      build_plan(h, n, tree, &split);
+      h->last_of_user = split.last_of_user;
+      h->first_of_user = split.first_of_user;
+      h->u_ni = split.u_ni;
+      h->u_nb = split.u_nb;
+      h->u_level = split.u_level;
+    } else {
+      build_plan(h, n, tree);
+    }
     std::vector<NodeH>& N = h->nodes;
     const int nlev = (int)h->levels.size() - 1;
     // depth(nd) in the reference counts levels; negative swlevel counts from the leaves (factorization.jl:8)
     int64_t swlevel = opts.swlevel < 0 ? std::max<int64_t>(nlev + opts.swlevel, 0) : opts.swlevel;
-    for (int i = 0; i < h->nreal; ++i)  // compression_flag of factorization.jl:15 (phase 1: low-rank Gauss transforms, hs_compress.h)
-      N[i].compressed = (N[i].level <= swlevel) && (N[i].nb >= opts.swsize) && N[i].nb > 0 && N[i].ni > 0 && !N[i].leaf;  // a compressed LEAF keeps dense L, R (factorization.jl:45-59)
+    for (int i = 0; i < h->nreal; ++i)  // compression_flag of factorization.jl:15 (hs_compress.h); levels of the USER's tree when fronts are split
+      N[i].compressed = split.active ? (split.cflag[i] != 0) : hs_compression_flag(N[i].level, N[i].ni, N[i].nb, N[i].leaf, swlevel, opts.swsize);
     for (auto& L : h->levels) {  // dense fronts first: they are eliminated as one batch, compressed fronts one by one
       std::vector<int> ord;
       for (int pass = 0; pass < 2; ++pass)
@@ -521,7 +563,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     h->int_elems = ints;
     if (plan_only) {  // host-side plan only (ownership, exchanges, sizes): no device is touched
       h->stats.n = n;
-      h->stats.nnodes = h->nreal;
+      h->stats.nnodes = h->nuser > 0 ? h->nuser : h->nreal;
       h->stats.nlevels = nlev;
       h->stats.bytes_factors = (double)(fac + inv) * sizeof(T);
       return h;
@@ -582,11 +624,12 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           continue;
         }
         bool is_left = (p.left == i);
-        int offi = is_left ? 0 : p.ni1, offb = is_left ? 0 : p.nb1;
+        // positions in the front the children address: [int; bnd] of the node, or of the user's node for a first slice
+        int offi = is_left ? 0 : p.oni1, offb = is_left ? 0 : p.onb1;
         int q = 0;
         for (int64_t e = tree->iloc_ptr[i]; e < tree->iloc_ptr[i + 1]; ++e, ++q) cm[tree->iloc_idx[e] - 1] = offi + q;
         q = 0;
-        for (int64_t e = tree->bloc_ptr[i]; e < tree->bloc_ptr[i + 1]; ++e, ++q) cm[tree->bloc_idx[e] - 1] = p.ni + offb + q;
+        for (int64_t e = tree->bloc_ptr[i]; e < tree->bloc_ptr[i + 1]; ++e, ++q) cm[tree->bloc_idx[e] - 1] = p.oni + offb + q;
       }
       HS_HIP(hipMemcpy(dint, hint.data(), ints * sizeof(int), hipMemcpyHostToDevice));
     }
@@ -619,6 +662,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           d.ni = x.ni; d.nb = x.nb; d.m = x.m;
           d.ldl = x.ldl; d.ldu = x.ldu; d.lds = x.lds;
           d.ni1 = x.ni1; d.nb1 = x.nb1;
+          d.s_ni = x.oni; d.s_ni1 = x.oni1; d.s_nb1 = x.onb1;
           d.isleaf = x.leaf ? 1 : 0;
           d.node = id;
           d.finalize();
@@ -666,7 +710,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
 
     hs_stats& st = h->stats;
     st.n = n;
-    st.nnodes = h->nreal;
+    st.nnodes = h->nuser > 0 ? h->nuser : h->nreal;
     st.nlevels = nlev;
     for (int i = 0; i < h->nnodes; ++i) {
       if (!N[i].mine) continue;
@@ -727,6 +771,7 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     const int nb_ = (int)L.mine.size();
     static const bool progress = getenv("HS_PROGRESS") != nullptr;  // one line per level as it is enqueued (long profiler runs)
     if (progress) fprintf(stderr, "[hs] enqueue level %d (%d fronts)\n", lv, nb_);
+    h->prof.tag = lv;
     hipEvent_t ea = h->prof.begin(s);
     // zero-fill this level's fronts: LF/UR are contiguous per level; SB of the owned fronts only
     // (a ghost child's SB holds received data and must survive)
@@ -785,6 +830,11 @@ static void numeric_end(hs_handle* h) {
         if (h->is_complex) fl *= 4.0;
         fprintf(stderr, "[hs] level %2d: %4zu fronts, max (ni,nb)=(%d,%d)  %9.3f ms  %8.2f TFLOP/s (minimal count)\n", le.first, L.mine.size(),
                 L.maxni, L.maxnb, lms, lms > 0 ? fl / (lms * 1e-3) / 1e12 : 0.0);
+        if (prof.on && le.first >= 0 && le.first < 64) {
+          const double* m = prof.ms_tag[le.first];
+          fprintf(stderr, "[hs]          per-launch events: gemm %.1f  panel %.1f  laswp %.1f  trsm %.1f  assemble %.1f ms\n", m[HS_CAT_GEMM], m[HS_CAT_PANEL],
+                  m[HS_CAT_LASWP], m[HS_CAT_TRSM], m[HS_CAT_ASSEMBLE]);
+        }
       }
       if (prev != h->ev0) (void)hipEventDestroy(prev);
       prev = le.second;
@@ -1072,12 +1122,37 @@ extern "C" int hs_extract_owned(const hs_handle* h, const void* d_b, void* d_out
 extern "C" int64_t hs_maxrank(const hs_handle* F) {
   return F ? F->maxrank : 0;  // max over fronts of rank(L), rank(R) (factornode.jl:49-57); 0 on the dense path
 }
+// node ids of the C ABI are post-order positions in the USER's tree (the pseudo-root follows them); with split fronts
+// (hs_split.h) a user node is a chain of internal nodes
+static inline bool hs_is_split(const hs_handle* F, int64_t node) {
+  return !F->last_of_user.empty() && node < F->nuser && F->first_of_user[node] != F->last_of_user[node];
+}
+static inline int hs_internal_id(const hs_handle* F, int64_t node) {
+  if (F->last_of_user.empty()) return (int)node;
+  return node < F->nuser ? F->last_of_user[node] : (int)(F->nreal + (node - F->nuser));
+}
+static inline int64_t hs_num_user_nodes(const hs_handle* F) { return F->last_of_user.empty() ? F->nnodes : F->nuser + (F->nnodes - F->nreal); }
+
 extern "C" int hs_node_ranks(const hs_handle* F, int64_t node, int64_t* rank_L, int64_t* rank_R) {
-  if (!F || node < 0 || node >= F->nnodes) {
+  if (!F || node < 0 || node >= hs_num_user_nodes(F)) {
     hs_set_error(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
     return HS_ERR_ARGUMENT;
   }
-  const NodeH& x = F->nodes[node];
+  if (hs_is_split(F, node)) {  // a front eliminated in slices: the largest ranks over its slices
+    int64_t rl = 0, rr = 0;
+    int any = 0;
+    for (int id = F->first_of_user[node]; id <= F->last_of_user[node]; ++id) {
+      const NodeH& y = F->nodes[id];
+      if (!(y.compressed && y.lrL && y.lrR)) continue;
+      any = 1;
+      rl = std::max<int64_t>(rl, F->is_complex ? ((const LowRank<cplx>*)y.lrL)->r : ((const LowRank<double>*)y.lrL)->r);
+      rr = std::max<int64_t>(rr, F->is_complex ? ((const LowRank<cplx>*)y.lrR)->r : ((const LowRank<double>*)y.lrR)->r);
+    }
+    if (rank_L) *rank_L = rl;
+    if (rank_R) *rank_R = rr;
+    return any;
+  }
+  const NodeH& x = F->nodes[hs_internal_id(F, node)];
   int64_t rl = 0, rr = 0;  // 0 = dense Gauss transform, like rank terms of maxrank (factornode.jl:54-55)
   if (x.compressed && x.lrL && x.lrR) {
     if (F->is_complex) {
@@ -1105,11 +1180,17 @@ extern "C" int hs_get_stats(const hs_handle* F, hs_stats* out) {
 }
 
 extern "C" int hs_node_info(const hs_handle* F, int64_t node, int64_t* ni, int64_t* nb, int64_t* level) {
-  if (!F || node < 0 || node >= F->nnodes) {
+  if (!F || node < 0 || node >= hs_num_user_nodes(F)) {
     hs_set_error(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
     return HS_ERR_ARGUMENT;
   }
-  const NodeH& x = F->nodes[node];
+  if (!F->last_of_user.empty() && node < F->nuser) {  // sizes and level of the user's node, however it is eliminated
+    if (ni) *ni = F->u_ni[node];
+    if (nb) *nb = F->u_nb[node];
+    if (level) *level = F->u_level[node];
+    return HS_OK;
+  }
+  const NodeH& x = F->nodes[hs_internal_id(F, node)];
   if (ni) *ni = x.ni;
   if (nb) *nb = x.nb;
   if (level) *level = x.level;
@@ -1141,13 +1222,16 @@ static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) 
 }
 
 extern "C" int hs_node_export(const hs_handle* F, int64_t node, int which, double* out) {
-  HS_GUARD(check_handle(F); if (node < 0 || node >= F->nnodes || !out) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
-           if (F->is_complex) export_block<cplx>(F, F->nodes[node], which, (cplx*)out); else export_block<double>(F, F->nodes[node], which, out));
+  HS_GUARD(check_handle(F); if (node < 0 || node >= hs_num_user_nodes(F) || !out) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+           if (hs_is_split(F, node)) HS_FAIL(HS_ERR_UNSUPPORTED, node, "node %lld is eliminated in slices (hs_options.split): it has no single D, L, R", (long long)node);
+           const NodeH& x = F->nodes[hs_internal_id(F, node)];
+           if (F->is_complex) export_block<cplx>(F, x, which, (cplx*)out); else export_block<double>(F, x, which, out));
 }
 
 extern "C" int hs_node_export_piv(const hs_handle* F, int64_t node, int64_t* out) {
-  HS_GUARD(check_handle(F); if (node < 0 || node >= F->nnodes || !out) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
-           const NodeH& x = F->nodes[node]; if (!x.mine) HS_FAIL(HS_ERR_ARGUMENT, node, "ArgumentError: node is owned by rank %d", x.owner);
+  HS_GUARD(check_handle(F); if (node < 0 || node >= hs_num_user_nodes(F) || !out) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+           if (hs_is_split(F, node)) HS_FAIL(HS_ERR_UNSUPPORTED, node, "node %lld is eliminated in slices (hs_options.split): it has no single D, L, R", (long long)node);
+           const NodeH& x = F->nodes[hs_internal_id(F, node)]; if (!x.mine) HS_FAIL(HS_ERR_ARGUMENT, node, "ArgumentError: node is owned by rank %d", x.owner);
            std::vector<int> tmp(x.ni);
            if (x.ni) HS_HIP(hipMemcpy(tmp.data(), F->d_int + x.off_rperm, x.ni * sizeof(int), hipMemcpyDeviceToHost));
            for (int i = 0; i < x.ni; ++i) out[i] = tmp[i]);

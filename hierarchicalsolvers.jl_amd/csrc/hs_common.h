@@ -80,6 +80,8 @@ struct NodeDesc {
   int ni, nb, m;
   int ldl, ldu, lds;
   int ni1, nb1;  // branch: sizes of the left child's contribution to int / bnd (front split points); leaf: ni, nb
+  int s_ni, s_ni1, s_nb1;  // the same three split points of the front the CHILDREN address (which child a front position came
+                           // from, for the gather): ni, ni1, nb1 except for the first slice of a split front (hs_split.h)
   int pivrows;   // pivot candidates are rows [c0, pivrows): ni for a front (`\\` on Aii pivots inside Aii only), all rows for a sketch
   int isleaf;
   int node;      // post-order id
@@ -90,6 +92,7 @@ struct NodeDesc {
   int mld[3], mrows[3], mcols[3];
   __host__ void finalize() {
     if (pivrows <= 0) pivrows = ni;
+    if (s_ni <= 0) { s_ni = ni; s_ni1 = ni1; s_nb1 = nb1; }
     mp[0] = LF; mp[1] = UR; mp[2] = SB;
     mld[0] = ldl; mld[1] = ldu; mld[2] = lds;
     mrows[0] = m; mrows[1] = ni; mrows[2] = nb;

@@ -22,8 +22,10 @@ struct Profiler {
     hipEvent_t e0, e1;
     int cat;
     double fl;
-    int M, N, K, nbatch;
+    int M, N, K, nbatch, tag;
   };
+  int tag = 0;                          // set by the caller (tree level): per-level sums for HS_VERBOSE_LEVELS
+  double ms_tag[64][HS_NCAT] = {};
   std::vector<Rec> recs;
   double flops[HS_NCAT] = {0, 0, 0, 0, 0};
   double ms[HS_NCAT] = {0, 0, 0, 0, 0};
@@ -43,14 +45,17 @@ struct Profiler {
     hipEvent_t e1;
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e1, s);
-    recs.push_back({e0, e1, cat, fl, M, N, K, nbatch});
+    recs.push_back({e0, e1, cat, fl, M, N, K, nbatch, tag});
   }
   void collect() {  // call after the stream has been synchronised
     const char* logf = getenv("HS_GEMM_LOG");  // diagnostics: one line per GEMM launch (max M, N, K of the batch, flops, ms)
     FILE* lf = (logf && on) ? fopen(logf, "a") : nullptr;
     for (auto& r : recs) {
       float t = 0.f;
-      if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) ms[r.cat] += t;
+      if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+        ms[r.cat] += t;
+        if (r.tag >= 0 && r.tag < 64) ms_tag[r.tag][r.cat] += t;
+      }
       if (lf && r.cat == HS_CAT_GEMM) fprintf(lf, "%d %d %d %d %.6g %.6f\n", r.M, r.N, r.K, r.nbatch, r.fl, t);
       (void)hipEventDestroy(r.e0);
       (void)hipEventDestroy(r.e1);

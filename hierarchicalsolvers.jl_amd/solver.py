@@ -31,7 +31,7 @@ class SolverOptions:
     ``5, 1, 1e-6, 1e-6, 0.5, 32, -1, 10, false`` (HierarchicalSolvers.jl:43-54)."""
 
     _fields = ("swlevel", "swsize", "atol", "rtol", "c_tol", "leafsize", "kest", "stepsize", "verbose")
-    _ext = ("keep_schur", "seed", "profile")
+    _ext = ("keep_schur", "seed", "profile", "split_size")
 
     def __init__(self, **kw):
         self.swlevel, self.swsize = 5, 1
@@ -41,6 +41,7 @@ class SolverOptions:
         self.keep_schur = False
         self.profile = False
         self.seed = 123
+        self.split_size = 0  # columns per slice of a compressed front's interior block (multiple of 256, 0 = off)
         self._set(kw)
 
     def _set(self, kw):
@@ -66,6 +67,10 @@ class SolverOptions:
         o.keep_schur = 1 if self.keep_schur else 0
         o.profile = 1 if self.profile else 0
         o.seed = int(self.seed)
+        ss = int(self.split_size)
+        if ss < 0 or ss % 256 or ss // 256 > 255:
+            raise ValueError("split_size must be a multiple of 256 in 0:65280")
+        o.split = ss // 256
         return o
 
 

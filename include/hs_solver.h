@@ -56,7 +56,10 @@ typedef struct hs_options {
   /* ---- extensions ---- */
   uint8_t keep_schur; /* debug: retain every node's Schur complement S for hs_node_export */
   uint8_t profile;    /* time every kernel launch with HIP events (fills hs_stats.t_gemm etc.; adds launch gaps) */
-  uint8_t reserved[5];
+  uint8_t split;      /* slice width, in units of 256 columns, in which the interior block of a compressed front (level <=
+                         swlevel, ni >= 2 slices) is eliminated: the role of the 2x2 BlockFactorization of D (blockmatrix.jl:106-130);
+                         0 = off; single-rank factorizations only */
+  uint8_t reserved[4];
   int64_t seed;       /* RNG seed of the randomized compression (reference: Random.seed!(123), test/rungmres.jl:7) */
 } hs_options;
 

@@ -127,3 +127,37 @@ def test_refactor_reuses_ranks_and_kest(hs):
     assert max(errs) < 1e-5, errs
     assert ranks[0] > 32  # the sketch had to grow beyond kest
     assert max(ranks) - min(ranks) <= 8, ranks  # the randomized rank decision is stable between passes
+
+
+SPLIT_CASES = [
+    ("poisson3d_32", {}, 3, 256),
+    ("poisson3d_32", {}, 2, 512),
+    ((20, 20, 20), dict(kind="helmholtz", nmax=200), 2, 256),
+    ("poisson2d_p1_h128_nmax100", {}, 3, 256),  # fronts too small to split: the option must be a no-op
+]
+
+
+@pytest.mark.parametrize("name,kw,swlevel,split", SPLIT_CASES)
+@pytest.mark.parametrize("tol", [1e-6, 1e-13])
+def test_split_fronts(hs, name, kw, swlevel, split, tol):
+    """hs_options.split: the interior block of a large compressed front is eliminated in slices (block LU of D with
+    low-rank off-diagonal panels -- the role of the reference's 2x2 BlockFactorization, blockmatrix.jl:106-130).
+    With a tolerance at round-off level the factorization is exact again; otherwise O(tol)."""
+    P = prepare(hs, name, rhs="randn", **kw)
+    xr = spla.splu(P["A"]).solve(P["b"])
+    F0 = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=swlevel, swsize=8, atol=tol, rtol=tol)
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=swlevel, swsize=8, atol=tol, rtol=tol, split_size=split)
+    e0, e = relerr(hs.ldiv(F0, P["b"]), xr), relerr(hs.ldiv(F, P["b"]), xr)
+    print(f"{name} tol={tol:g} split={split}: err {e:.2e} (unsplit {e0:.2e}) maxrank {hs.maxrank(F)} (unsplit {hs.maxrank(F0)})")
+    assert e <= max(30 * e0, 300 * tol, 1e-10), (e, e0)
+    # node ids, sizes and levels seen through the API are those of the user's tree
+    root = F.nnodes - 1
+    assert F.node_info(root) == F0.node_info(root)
+    comp, rl, rr = F.node_ranks(root)
+    ni, nb, _ = F.node_info(root)
+    if ni >= 2 * split:
+        assert comp and rl > 0 and rr > 0  # the root itself has no boundary, its slices do
+        with pytest.raises(hs.UnsupportedError):
+            F.node_blocks(root)
+    x, ch = hs.gmres(P["A"], P["b"], Pr=F, reltol=1e-10, restart=30, maxiter=30, log=True)
+    assert ch["isconverged"] and ch["iters"] <= (3 if tol < 1e-10 else 8)
