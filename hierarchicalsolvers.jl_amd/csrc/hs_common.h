@@ -153,8 +153,6 @@ template <class T>
 void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, int fuse, hipStream_t s);
 template <class T>
 void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1, int k0, int k1, int maxcols, hipStream_t s);
-template <class T>
-void launch_trsm_blk(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int c0, int c1, int maxcols, hipStream_t s);
 
 template <class T>
 void launch_init_fronts(const NodeDesc<T>* dnodes, int nbatch, int maxni, hipStream_t s);  // rperm = 0:ni-1, info = 0

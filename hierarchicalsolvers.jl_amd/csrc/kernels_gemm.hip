@@ -407,17 +407,10 @@ struct TileCfg<cplx> {
   static constexpr int smem_doubles = 2 * BK * LDS_LD + 2 * ZBN * ZLDB;
 };
 
-// Two workgroups share a CU (one wave of each per SIMD).  Started together they run in lockstep: all
-// eight waves stage/barrier at the same moments and the MFMA pipe idles ~40 % (SQ_VALU_MFMA_BUSY_CYCLES
-// 59 %, SQ_WAIT_ANY 33 % on 8192^3).  Delaying every second workgroup of a CU by about half a K-step
-// lets one wave's MFMAs cover the other's staging.  Placement-dependent for speed only.
-__device__ int g_gemm_stagger = 0;
+
 
 template <class T>
 __device__ inline void gemm_dispatch(const GemmProb<T>& p, bool minus, double* smem) {
-  if (g_gemm_stagger > 0 && ((blockIdx.x >> 8) & 1)) {
-    for (int i = 0; i < g_gemm_stagger; ++i) __builtin_amdgcn_s_sleep(8);  // 8 * 64 cycles
-  }
   int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + TileCfg<T>::bn - 1) / TileCfg<T>::bn;
   int ntiles = tiles_m * tiles_n;
   // a launch may be capped to fewer workgroups than tiles (GemmOp::cap): each workgroup then walks the tiles
@@ -459,7 +452,6 @@ __global__ __launch_bounds__(256, 2) void gemm_probs_kernel(const GemmProb<T>* _
   gemm_dispatch<T>(p, minus != 0, smem);
 }
 
-static void set_stagger_once();
 
 template <class T>
 __global__ void resolve_dump_kernel(const NodeDesc<T>* __restrict__ nodes, GemmOp op, GemmProb<T>* out, int* ok) {
@@ -500,7 +492,6 @@ void launch_gemm_op(const NodeDesc<T>* dnodes, int nbatch, int maxM, int maxN, c
       (void)hipFree(dok);
     }
   }
-  set_stagger_once();
   int tiles = ((maxM + BM - 1) / BM) * ((maxN + TileCfg<T>::bn - 1) / TileCfg<T>::bn);
   if (op.cap > 0 && tiles > op.cap) tiles = std::max(8, op.cap / 8 * 8);
   constexpr int lds_bytes = TileCfg<T>::smem_doubles * 8;
@@ -515,19 +506,10 @@ void launch_gemm_op(const NodeDesc<T>* dnodes, int nbatch, int maxM, int maxN, c
   else
     hipLaunchKernelGGL(gemm_op_kernel<T>, dim3(tiles, nbatch), dim3(256), lds_bytes, s, dnodes, op);
 }
-static void set_stagger_once() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-  const char* e = getenv("HS_GEMM_STAGGER");
-  int v = e ? atoi(e) : 0;
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stagger), &v, sizeof v);
-}
 
 template <class T>
 void launch_gemm_probs(const GemmProb<T>* dprobs, int nprob, int maxM, int maxN, int minus, hipStream_t s) {
   if (nprob <= 0 || maxM <= 0 || maxN <= 0) return;
-  set_stagger_once();
   int tiles = ((maxM + BM - 1) / BM) * ((maxN + TileCfg<T>::bn - 1) / TileCfg<T>::bn);
   constexpr int lds_bytes = TileCfg<T>::smem_doubles * 8;
   static bool attr_set = false;

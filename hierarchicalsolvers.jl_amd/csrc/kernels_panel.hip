@@ -16,7 +16,7 @@
 //      top block in LDS and invert its L and U factors (kept for TRSM-by-GEMM and for ldiv!).
 //   3. panel_l21: every row below (including the Abi rows, which gives L_bi = Abi*U^-1 for free)
 //      is multiplied by inv(U11).
-//   laswp / trsm_blk apply the swaps and inv(L11) to the other columns as the recursion demands.
+//   laswp applies the swaps to the other columns as the recursion demands (inv(L11) goes through the MFMA tile code: trsm_inv_kernel).
 //
 // All kernels are "grouped": blockIdx.y selects the front of the current level batch.
 #include "hs_common.h"
@@ -451,41 +451,6 @@ __global__ __launch_bounds__(256) void laswp_kernel(const NodeDesc<T>* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// trsm_blk: X[r0:r0+32, c0:c1) <- inv(L11[r0/32]) * X[r0:r0+32, c0:c1)   (one column per thread)
-// ------------------------------------------------------------------------------------------------
-template <class T>
-__global__ __launch_bounds__(256) void trsm_blk_kernel(const NodeDesc<T>* __restrict__ nodes, int mat, int r0, int c0, int c1) {
-  const NodeDesc<T> nd = nodes[blockIdx.y];
-  if (r0 >= nd.ni) return;
-  T* p;
-  int ld, rows, cols;
-  mat_of(nodes + blockIdx.y, mat, p, ld, rows, cols);
-  c1 = min(c1, cols);
-  if (c0 + (int)blockIdx.x * 256 >= c1) return;
-  const int w = min(HS_PB, nd.ni - r0);
-  __shared__ T s_il[HS_PB * HS_PB];
-  const int pb = r0 / HS_PB;
-  for (int e = threadIdx.x; e < HS_PB * HS_PB; e += 256) s_il[e] = nd.invL[(size_t)pb * HS_PB * HS_PB + e];
-  __syncthreads();
-  const int c = c0 + blockIdx.x * 256 + threadIdx.x;
-  if (c >= c1) return;
-  T* x = p + (size_t)r0 + (size_t)c * ld;
-  T a[HS_PB];
-#pragma unroll
-  for (int i = 0; i < HS_PB; ++i) a[i] = (i < w) ? x[i] : Scal<T>::zero();
-#pragma unroll
-  for (int i = 0; i < HS_PB; ++i) {
-    if (i < w) {
-      T s = Scal<T>::zero();
-#pragma unroll
-      for (int j = 0; j < HS_PB; ++j)
-        if (j <= i) s = Scal<T>::fma(s_il[i + j * HS_PB], a[j], s);
-      x[i] = s;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -508,17 +473,12 @@ void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1
   if (nbatch <= 0 || maxcols <= 0 || k1 <= k0) return;
   hipLaunchKernelGGL(laswp_kernel<T>, dim3((maxcols + 255) / 256, nbatch), dim3(256), 0, s, dnodes, mat, c0, c1, k0, k1);
 }
-template <class T>
-void launch_trsm_blk(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int c0, int c1, int maxcols, hipStream_t s) {
-  if (nbatch <= 0 || maxcols <= 0) return;
-  hipLaunchKernelGGL(trsm_blk_kernel<T>, dim3((maxcols + 255) / 256, nbatch), dim3(256), 0, s, dnodes, mat, r0, c0, c1);
-}
 
 #define INST(T)                                                                                         \
   template void launch_tournament_round<T>(const NodeDesc<T>*, int, int, int, int, hipStream_t);        \
   template void launch_panel_pivot<T>(const NodeDesc<T>*, int, int, int, hipStream_t);                       \
   template void launch_panel_l21<T>(const NodeDesc<T>*, int, int, int, int, hipStream_t);                    \
   template void launch_laswp<T>(const NodeDesc<T>*, int, int, int, int, int, int, int, hipStream_t);    \
-  template void launch_trsm_blk<T>(const NodeDesc<T>*, int, int, int, int, int, int, hipStream_t);
+
 INST(double)
 INST(cplx)
