@@ -221,6 +221,11 @@ def main():
         }
         if flops:
             out["factor_tflops_minimal_count"] = flops / st["t_total"] / 1e12
+        if world == 1 and st["t_solve"] > 0:
+            # ldiv! is HBM-bound: every stored factor entry is read once per right-hand side
+            gbs = st["bytes_solve"] / st["t_solve"] / 1e9
+            out["solve"] = {"seconds": st["t_solve"], "algorithmic_bytes": st["bytes_solve"], "achieved_GBps": gbs,
+                            "frac_of_measured_copy_bw_6290GBps": gbs / 6290.0}
         if roofline:
             out["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:

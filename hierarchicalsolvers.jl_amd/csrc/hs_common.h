@@ -112,6 +112,7 @@ struct GemmOp {
   int ainv;        // 1: A = invL[r0/32] (32x32), C = A*B in place on rows [r0, r0+32): the TRSM base case; 2: A = invU[r0/32]
   int cap;         // > 0: launch at most this many workgroups per front (they walk the tiles): leaves CU slots free for a
                    // concurrent stream (the look-ahead panel chain); 0: one workgroup per tile
+  int prio;        // 1: raise the waves' issue priority (s_setprio): panel work of the look-ahead side stream
 };
 
 // plain problem (test hooks, root Schur, compressed path)

@@ -77,6 +77,7 @@ struct Sched {
   int maxpiv = 0;            // largest pivot-candidate row limit in the batch (0: = maxni)
   hipStream_t s_la = nullptr;  // optional CU-masked pair for the look-ahead schedule: s_la = every CU but a reserved
   hipStream_t s2m = nullptr;   // few, s2m = the reserved ones
+  int hiprio = 0;              // 1: this schedule is the look-ahead side stream (its GEMMs raise their wave priority)
 
   // HS_DEBUG_SYNC=1: synchronise after every launch and report the first failing one (diagnostics only)
   void dbg(const char* what, int a = 0, int b = 0, int c = 0, int d = 0) {
@@ -99,7 +100,7 @@ struct Sched {
   int cols_of(int mat) const { return mat == HS_MAT_LF ? maxni : maxnb; }
 
   void gemm(int cmat, int bmat, int r0, int r1, int c0, int c1, int k0, int k1, int cap = 0) {
-    GemmOp op{cmat, bmat, r0, r1, c0, c1, k0, k1, 0, cap};
+    GemmOp op{cmat, bmat, r0, r1, c0, c1, k0, k1, 0, cap, hiprio};
     int M = std::min(r1, rows_of(cmat)) - r0, N = std::min(c1, cols_of(cmat)) - c0, K = std::min(k1, maxni) - k0;
     if (M <= 0 || N <= 0 || K <= 0) return;
     double fl = 0.0;
@@ -250,6 +251,7 @@ struct Sched {
     side.s = s2;
     side.s2 = nullptr;
     side.s_la = nullptr;
+    side.hiprio = 1;
     if (s_la) {
       (void)hipStreamWaitEvent(s2, ev_main, 0);
       side.lu_rec(0, NB);

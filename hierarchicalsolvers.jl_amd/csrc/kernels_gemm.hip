@@ -431,6 +431,7 @@ template <class T>
 __global__ __launch_bounds__(256, 2) void gemm_op_kernel(const NodeDesc<T>* __restrict__ nodes, GemmOp op) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   GemmProb<T> p;
+  if (op.prio) __builtin_amdgcn_s_setprio(2);  // look-ahead panel work sharing CUs with the big trailing update
   if (!resolve_op(nodes + blockIdx.y, op, p)) return;
   gemm_dispatch<T>(p, true, smem);
 }
@@ -440,6 +441,7 @@ template <class T>
 __global__ __launch_bounds__(256, 2) void trsm_inv_kernel(const NodeDesc<T>* __restrict__ nodes, GemmOp op) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   GemmProb<T> p;
+  __builtin_amdgcn_s_setprio(2);
   if (!resolve_op(nodes + blockIdx.y, op, p)) return;
   gemm_dispatch<T>(p, false, smem);
 }

@@ -62,6 +62,7 @@ __device__ inline cplx lane_bcast(cplx v, int lane) { return {lane_bcast(v.re, l
 
 template <class T>
 __global__ __launch_bounds__(HS_CHUNK) void tournament_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int round) {
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win instruction issue over co-resident GEMM waves
   const NodeDesc<T> nd = nodes[blockIdx.y];
   const int c0 = pb * HS_PB;
   if (c0 >= nd.ni) return;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(HS_CHUNK) void tournament_kernel(const NodeDesc<T>*
 // ------------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int fuse) {
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win instruction issue over co-resident GEMM waves
   const NodeDesc<T> nd = nodes[blockIdx.y];
   const int c0 = pb * HS_PB;
   if (c0 >= nd.ni) return;
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
 // ------------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int fuse) {
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win instruction issue over co-resident GEMM waves
   const NodeDesc<T> nd = nodes[blockIdx.y];
   const int c0 = pb * HS_PB;
   if (c0 >= nd.ni) return;
@@ -431,6 +434,7 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
 // ------------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void laswp_kernel(const NodeDesc<T>* __restrict__ nodes, int mat, int c0, int c1, int k0, int k1) {
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win instruction issue over co-resident GEMM waves
   const NodeDesc<T> nd = nodes[blockIdx.y];
   T* p;
   int ld, rows, cols;
