@@ -123,6 +123,7 @@ struct NodeH {
   int kind = 0;                  // hs_split.h: 0 ordinary, 1 first slice of a split front, 2 later slice
   int user = -1;                 // user (post-order) node id this internal node belongs to
   int oni = 0, oni1 = 0, onb1 = 0;  // split points of the front the children address (= ni, ni1, nb1 unless kind 1)
+  long long off_spos = -1;          // kind 1 with re-ordered interior: int offset of the slice-order -> original-position table
 };
 
 struct LevelH {
@@ -446,7 +447,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     memset(&h->stats, 0, sizeof h->stats);
     h->nuser = tree ? (int)tree->nnodes : 0;
     SplitTree split;
-    make_split_tree(tree, opts, nranks, split);  // hs_split.h: large compressed fronts are eliminated in slices
+    make_split_tree(tree, opts, nranks, split, n, plan_only ? nullptr : colptr, plan_only ? nullptr : rowval);  // hs_split.h: large compressed fronts are eliminated in slices
     if (split.active) {
       build_plan(h, n, tree);  // validates the user's tree (same errors as without slices) ...
       free_lowrank_any(h);
@@ -528,6 +529,10 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         ints += x.ni;
         x.off_rperm = ints;
         ints += x.ni;
+        if (split.active && x.kind == 1 && !split.newpos[id].empty()) {  // slice order -> original position of the interior DOFs
+          x.off_spos = (long long)ints;
+          ints += x.oni;
+        }
         x.ncand = ((x.ni + HS_CHUNK - 1) / HS_CHUNK + 1) * HS_PB;
         x.off_cand = tmpi;
         tmpi += (size_t)2 * x.ncand + HS_PB;
@@ -626,10 +631,19 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         bool is_left = (p.left == i);
         // positions in the front the children address: [int; bnd] of the node, or of the user's node for a first slice
         int offi = is_left ? 0 : p.oni1, offb = is_left ? 0 : p.onb1;
+        // a first slice with re-ordered interior: original int position -> position in the slice order (hs_split.h)
+        const int* np = (split.active && p.kind == 1 && !split.newpos[x.parent].empty()) ? split.newpos[x.parent].data() : nullptr;
         int q = 0;
-        for (int64_t e = tree->iloc_ptr[i]; e < tree->iloc_ptr[i + 1]; ++e, ++q) cm[tree->iloc_idx[e] - 1] = offi + q;
+        for (int64_t e = tree->iloc_ptr[i]; e < tree->iloc_ptr[i + 1]; ++e, ++q) cm[tree->iloc_idx[e] - 1] = np ? np[offi + q] : offi + q;
         q = 0;
         for (int64_t e = tree->bloc_ptr[i]; e < tree->bloc_ptr[i + 1]; ++e, ++q) cm[tree->bloc_idx[e] - 1] = p.oni + offb + q;
+      }
+      for (int i = 0; i < h->nnodes; ++i) {  // slice order -> original position tables (which child a front position came from)
+        NodeH& x = N[i];
+        if (x.off_spos < 0) continue;
+        const std::vector<int>& np = split.newpos[i];
+        int* sp = hint.data() + x.off_spos;
+        for (int e = 0; e < x.oni; ++e) sp[np[e]] = e;
       }
       HS_HIP(hipMemcpy(dint, hint.data(), ints * sizeof(int), hipMemcpyHostToDevice));
     }
@@ -663,6 +677,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           d.ldl = x.ldl; d.ldu = x.ldu; d.lds = x.lds;
           d.ni1 = x.ni1; d.nb1 = x.nb1;
           d.s_ni = x.oni; d.s_ni1 = x.oni1; d.s_nb1 = x.onb1;
+          d.spos = x.off_spos >= 0 ? dint + x.off_spos : nullptr;
           d.isleaf = x.leaf ? 1 : 0;
           d.node = id;
           d.finalize();

@@ -80,6 +80,7 @@ struct NodeDesc {
   int ni, nb, m;
   int ldl, ldu, lds;
   int ni1, nb1;  // branch: sizes of the left child's contribution to int / bnd (front split points); leaf: ni, nb
+  const int* spos;         // first slice of a split front with re-ordered interior: position < s_ni -> original position; else null
   int s_ni, s_ni1, s_nb1;  // the same three split points of the front the CHILDREN address (which child a front position came
                            // from, for the gather): ni, ni1, nb1 except for the first slice of a split front (hs_split.h)
   int pivrows;   // pivot candidates are rows [c0, pivrows): ni for a front (`\\` on Aii pivots inside Aii only), all rows for a sketch

@@ -32,6 +32,7 @@ __device__ inline void front_store(const NodeDesc<T>& nd, int P, int Q, T v) {
 template <class T>
 __device__ inline int side_of(const NodeDesc<T>& nd, int p) {
   if (nd.isleaf) return 0;
+  if (nd.spos && p < nd.s_ni) p = nd.spos[p];
   if (p < nd.s_ni) return (p < nd.s_ni1) ? 1 : 2;
   return (p - nd.s_ni < nd.s_nb1) ? 1 : 2;
 }
