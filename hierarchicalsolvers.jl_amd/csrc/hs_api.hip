@@ -110,7 +110,7 @@ struct NodeH {
   bool mine = true;    // owner == my rank
   bool ghost = false;  // not mine, but one of my fronts absorbs its Schur complement (received from its owner)
   int ldl = 0, ldu = 0, lds = 0;
-  size_t off_LF = 0, off_UR = 0, off_SB = 0, off_inv = 0;                        // element offsets
+  size_t off_LF = 0, off_UR = 0, off_SB = 0, off_inv = 0, off_inv256 = 0;        // element offsets
   size_t off_fidx = 0, off_ipiv = 0, off_rperm = 0, off_cmap = 0, off_cand = 0;  // int offsets
   int ncand = 0;
   int batch_pos = -1;      // index inside its level's batch of owned fronts
@@ -525,6 +525,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         int nblk = (x.ni + HS_PB - 1) / HS_PB;
         x.off_inv = inv;
         inv += (size_t)2 * nblk * HS_PB * HS_PB;
+        x.off_inv256 = inv;  // inverses of the 256 x 256 diagonal blocks of L and U (wide sweeps of ldiv!)
+        inv += (size_t)2 * ((x.ni + 255) / 256) * 256 * 256;
         x.off_ipiv = ints;
         ints += x.ni;
         x.off_rperm = ints;
@@ -685,6 +687,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           SolveNode<T> q;
           memset(&q, 0, sizeof q);
           q.LF = d.LF; q.UR = d.UR; q.invL = d.invL; q.invU = d.invU;
+          q.inv256L = dinv + x.off_inv256;
+          q.inv256U = q.inv256L + (size_t)((x.ni + 255) / 256) * 256 * 256;
           q.rperm = d.rperm; q.fidx = d.fidx;
           q.ni = x.ni; q.nb = x.nb; q.m = x.m; q.ldl = x.ldl; q.ldu = x.ldu;
           q.compressed = x.compressed ? 1 : 0;
@@ -811,6 +815,7 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
       sch.factor_fronts();
     }
     if (nb_ > L.ndense) factor_compressed_level<T>(h, L.mine.data() + L.ndense, nb_ - L.ndense, dn + L.ndense);  // hs_compress.h
+    launch_inv256<T>((const SolveNode<T>*)h->d_solve + L.desc_off, nb_, L.maxni, s);  // for the 256-column sweeps of ldiv!
     static const bool lvl_env = getenv("HS_VERBOSE_LEVELS") != nullptr;
     if (h->opts.profile || lvl_env) {  // per-level wall time (HS_VERBOSE_LEVELS=1 prints it at hs_numeric_end)
       hipEvent_t e = nullptr;
@@ -891,8 +896,14 @@ static void solve_fwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
     const SolveNode<T>* dn = sn + L.desc_off;
     const int nb_ = (int)L.mine.size();
     launch_fwd_gather<T>(dn, nb_, L.maxni, db, w1, s);
-    const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
-    for (int blk = 0; blk < nblk; ++blk) launch_fwd_step<T>(dn, nb_, blk, L.maxm, w1, w2, db, s);
+    static const bool wide = !(getenv("HS_SOLVE_WIDE") && getenv("HS_SOLVE_WIDE")[0] == '0');  // 256 columns per launch (kernels_solve_wide.hip)
+    if (wide) {
+      const int nblk = (L.maxni + hs_solve_wide_cols() - 1) / hs_solve_wide_cols();
+      for (int blk = 0; blk < nblk; ++blk) launch_fwd_wide<T>(dn, nb_, blk, L.maxm, w1, w2, db, s);
+    } else {
+      const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
+      for (int blk = 0; blk < nblk; ++blk) launch_fwd_step<T>(dn, nb_, blk, L.maxm, w1, w2, db, s);
+    }
     solve_lr_fwd<T>(h, lv, db, s);
   }
 }
@@ -913,7 +924,13 @@ static void solve_bwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
     launch_int_update<T>(dn, nb_, L.maxni, L.maxnb, db, part, w2, w1, s);
     solve_lr_bwd<T>(h, lv, db, s);
     const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
-    for (int blk = nblk - 1; blk >= 0; --blk) launch_bwd_step<T>(dn, nb_, blk, w1, w2, s);
+    static const bool wide = !(getenv("HS_SOLVE_WIDE") && getenv("HS_SOLVE_WIDE")[0] == '0');
+    if (wide) {
+      const int nw = (L.maxni + hs_solve_wide_cols() - 1) / hs_solve_wide_cols();
+      for (int blk = nw - 1; blk >= 0; --blk) launch_bwd_wide<T>(dn, nb_, blk, w1, w2, s);
+    } else {
+      for (int blk = nblk - 1; blk >= 0; --blk) launch_bwd_step<T>(dn, nb_, blk, w1, w2, s);
+    }
     launch_bwd_scatter<T>(dn, nb_, L.maxni, db, w2, s);
   }
 }

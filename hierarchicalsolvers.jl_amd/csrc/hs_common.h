@@ -180,6 +180,8 @@ struct SolveNode {
   const T* UR;
   const T* invL;
   const T* invU;
+  T* inv256L;        // ceil(ni/256) blocks of 256 x 256 (column-major): inverses of the diagonal blocks of L (kernels_solve_wide.hip)
+  T* inv256U;        // same for U
   const int* rperm;  // ni: (P x)[i] = x[rperm[i]]
   const int* fidx;   // m global ids (0-based), front order [int; bnd]
   int ni, nb, m, ldl, ldu;
@@ -196,6 +198,14 @@ template <class T>
 void launch_int_update(const SolveNode<T>* dn, int nbatch, int maxni, int maxnb, const T* b, T* part, const T* y, T* w, hipStream_t s);
 template <class T>
 void launch_bwd_step(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s);
+// the same sweeps 256 columns per launch (kernels_solve_wide.hip)
+template <class T>
+void launch_fwd_wide(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w, T* y, T* b, hipStream_t s);
+template <class T>
+void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s);
+template <class T>
+void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s);
+int hs_solve_wide_cols();
 template <class T>
 void launch_bwd_scatter(const SolveNode<T>* dn, int nbatch, int maxni, T* b, const T* x, hipStream_t s);
 
