@@ -668,6 +668,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           int nblk = (x.ni + HS_PB - 1) / HS_PB;
           d.invL = dinv + x.off_inv;
           d.invU = dinv + x.off_inv + (size_t)nblk * HS_PB * HS_PB;
+          d.inv256L = dinv + x.off_inv256;
+          d.inv256U = d.inv256L + (size_t)((x.ni + 255) / 256) * 256 * 256;
           d.ipiv = dint + x.off_ipiv;
           d.rperm = dint + x.off_rperm;
           d.cand0 = h->d_tmpi + x.off_cand;
@@ -812,10 +814,10 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     h->prof.end(ea, HS_CAT_ASSEMBLE, s);
     if (L.ndense > 0) {
       Sched<T> sch{dn, L.ndense, L.dmaxni, L.dmaxnb, L.dmaxm, s, &h->prof, L.h_ni.data(), L.h_nb.data(), h->stream2, 0, h->stream_la, h->stream2m};
+      sch.sn = (const SolveNode<T>*)h->d_solve + L.desc_off;  // lu_rec leaves the 256x256 inverse diagonal blocks behind
       sch.factor_fronts();
     }
-    if (nb_ > L.ndense) factor_compressed_level<T>(h, L.mine.data() + L.ndense, nb_ - L.ndense, dn + L.ndense);  // hs_compress.h
-    launch_inv256<T>((const SolveNode<T>*)h->d_solve + L.desc_off, nb_, L.maxni, s);  // for the 256-column sweeps of ldiv!
+    if (nb_ > L.ndense) factor_compressed_level<T>(h, L.mine.data() + L.ndense, nb_ - L.ndense, dn + L.ndense, (const SolveNode<T>*)h->d_solve + L.desc_off + L.ndense);  // hs_compress.h
     static const bool lvl_env = getenv("HS_VERBOSE_LEVELS") != nullptr;
     if (h->opts.profile || lvl_env) {  // per-level wall time (HS_VERBOSE_LEVELS=1 prints it at hs_numeric_end)
       hipEvent_t e = nullptr;

@@ -70,6 +70,8 @@ struct NodeDesc {
   T* SB;
   T* invL;       // ceil(ni/32) blocks of 32x32 (column-major, ld 32): inverse of the unit-lower diagonal block
   T* invU;       // same for the upper diagonal block
+  T* inv256L;    // ceil(ni/256) blocks of 256x256 (ld 256): inverses of the 256x256 diagonal blocks of L (null: not kept)
+  T* inv256U;    // same for U.  Built as soon as the 256 columns are factored (kernels_solve_wide.hip): TRSM base case + ldiv!
   int* ipiv;     // ni entries: LAPACK-style swap targets (0-based row inside the front)
   int* rperm;    // ni entries: accumulated row permutation, (P x)[i] = x[rperm[i]] (used by ldiv!)
   int* cand0;    // tournament candidate lists (ping-pong)
@@ -110,7 +112,8 @@ struct GemmOp {
   int r0, r1;      // C rows   (A rows are the same, shifted by ni when C is SB)
   int c0, c1;      // C cols = B cols
   int k0, k1;      // A cols = B rows (always inside [0, ni))
-  int ainv;        // 1: A = invL[r0/32] (32x32), C = A*B in place on rows [r0, r0+32): the TRSM base case; 2: A = invU[r0/32]
+  int ainv;        // 1: A = invL[r0/32] (32x32), C = A*B in place on rows [r0, r0+32): the TRSM base case; 2: A = invU[r0/32];
+                   // 3..6: the 256-row base case through inv256L / inv256U, as two in-place half products (resolve_op)
   int cap;         // > 0: launch at most this many workgroups per front (they walk the tiles): leaves CU slots free for a
                    // concurrent stream (the look-ahead panel chain); 0: one workgroup per tile
   int prio;        // 1: raise the waves' issue priority (s_setprio): panel work of the look-ahead side stream
@@ -204,7 +207,7 @@ void launch_fwd_wide(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w
 template <class T>
 void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s);
 template <class T>
-void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s);
+void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s, int only_block = -1);
 int hs_solve_wide_cols();
 template <class T>
 void launch_bwd_scatter(const SolveNode<T>* dn, int nbatch, int maxni, T* b, const T* x, hipStream_t s);

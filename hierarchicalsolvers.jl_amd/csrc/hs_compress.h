@@ -54,7 +54,7 @@ static void free_lowrank_any(hs_handle* h) {
 // `ids` their node ids.  Steps A, C, D, E run as ONE batch over the fronts (the panel chains of single fronts would
 // otherwise run back to back); B and F are per front.
 template <class T>
-static void factor_compressed_level(hs_handle* h, const int* ids, int count, const NodeDesc<T>* dn) {
+static void factor_compressed_level(hs_handle* h, const int* ids, int count, const NodeDesc<T>* dn, const SolveNode<T>* sn) {
   if (count <= 0) return;
   hipStream_t s = h->stream;
   static const bool vt = getenv("HS_VERBOSE_COMPRESS") != nullptr;  // per-step wall times (diagnostics; adds syncs)
@@ -98,6 +98,7 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
     std::vector<int> hni(count), hnb(count, 0);
     for (int i = 0; i < count; ++i) hni[i] = hd[i].ni;
     Sched<T> sA{dd, count, maxni, 0, maxni, s, &h->prof, hni.data(), hnb.data(), h->stream2, 0, h->stream_la, h->stream2m};
+    sA.sn = sn;  // solve descriptors of the same fronts: the 256x256 inverse diagonal blocks are built inside lu_rec
     sA.factor_fronts();
   }
   lap("A: LU(Aii)");
@@ -164,6 +165,7 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
       }
       HS_HIP(hipMemcpy(dd + count, tmp.data(), sizeof(NodeDesc<T>) * count, hipMemcpyHostToDevice));
       Sched<T> sG{dd + count, count, maxni, maxrR, maxni, s, &h->prof, nullptr, nullptr};
+      sG.wide = true;  // step A left inv256L / inv256U of every front behind
       sG.laswp(HS_MAT_UR, 0, HS_BIG, 0, P2);
       sG.trsm_rec(HS_MAT_UR, 0, P2, 0, HS_BIG);
       lap("C: G = L^-1 P C_R");
@@ -179,6 +181,7 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
         }
         HS_HIP(hipMemcpy(dd + 2 * count, tmp.data(), sizeof(NodeDesc<T>) * count, hipMemcpyHostToDevice));
         Sched<T> sW{dd + 2 * count, count, maxni, maxrR, maxni, s, &h->prof, nullptr, nullptr};
+        sW.wide = true;
         sW.utrsm_rec(HS_MAT_UR, 0, P2, 0, HS_BIG);
         lap("D: W = U^-1 G");
         // E. S -= C_L * ((Z_L * W) * Z_R): three grouped GEMMs over the fronts

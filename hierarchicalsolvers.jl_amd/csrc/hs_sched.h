@@ -78,6 +78,9 @@ struct Sched {
   hipStream_t s_la = nullptr;  // optional CU-masked pair for the look-ahead schedule: s_la = every CU but a reserved
   hipStream_t s2m = nullptr;   // few, s2m = the reserved ones
   int hiprio = 0;              // 1: this schedule is the look-ahead side stream (its GEMMs raise their wave priority)
+  const SolveNode<T>* sn = nullptr;  // solve descriptors of the same batch: lu_rec leaves the inverses of the 256x256 diagonal
+                                     // blocks of L and U behind (TRSM base case of 256 rows; ldiv! sweeps); null = 32-row base only
+  bool wide = false;                 // the descriptors carry valid inv256L / inv256U for the rows being solved
 
   // HS_DEBUG_SYNC=1: synchronise after every launch and report the first failing one (diagnostics only)
   void dbg(const char* what, int a = 0, int b = 0, int c = 0, int d = 0) {
@@ -160,10 +163,25 @@ struct Sched {
     dbg("laswp", mat, c0, k0, k1);
   }
   // X[r0:r1, c0:c1) <- L[r0:r1, r0:r1]^-1 X
+  // 256-row base case: multiply by the stored inverse of the 256x256 diagonal block, two in-place half products
+  void trsm256(int mat, int r0, int c0, int c1, int nc, bool upper) {
+    const int first = upper ? 5 : 3, second = upper ? 6 : 4;
+    for (int code : {first, second}) {
+      GemmOp op{mat, mat, r0, r0 + 256, c0, c1, 0, 0, code};
+      hipEvent_t e0 = pf->begin(s);
+      launch_gemm_op<T>(dn, nbatch, 128, nc, op, s);
+      pf->end(e0, HS_CAT_TRSM, s);
+      dbg("trsm256", mat, r0, c0, code);
+    }
+  }
   void trsm_rec(int mat, int r0, int r1, int c0, int c1) {
     if (r0 >= maxni) return;
     int nc = std::min(c1, cols_of(mat)) - c0;
     if (nc <= 0) return;
+    if (r1 - r0 == 256 && (sn || wide)) {
+      trsm256(mat, r0, c0, c1, nc, false);
+      return;
+    }
     if (r1 - r0 == HS_PB) {
       // base case: multiply by the stored inverse of the 32x32 unit-lower diagonal block (MFMA GEMM, in place)
       GemmOp op{mat, mat, r0, r0 + HS_PB, c0, c1, 0, 0, 1};
@@ -185,6 +203,10 @@ struct Sched {
     if (r0 >= maxni) return;
     int nc = std::min(c1, cols_of(mat)) - c0;
     if (nc <= 0) return;
+    if (r1 - r0 == 256 && (sn || wide)) {
+      trsm256(mat, r0, c0, c1, nc, true);
+      return;
+    }
     if (r1 - r0 == HS_PB) {
       GemmOp op{mat, mat, r0, r0 + HS_PB, c0, c1, 0, 0, 2};
       hipEvent_t e0 = pf->begin(s);
@@ -202,6 +224,10 @@ struct Sched {
   }
   void lu_rec(int c0, int c1) {
     if (c0 >= maxni) return;
+    lu_rec_inner(c0, c1);
+    if (sn && c1 - c0 == 256) launch_inv256<T>(sn, nbatch, maxni, s, c0 / 256);  // the block is final: leave its inverses behind
+  }
+  void lu_rec_inner(int c0, int c1) {
     if (c1 - c0 == HS_PB) {
       panel(c0 / HS_PB);
       return;
@@ -314,6 +340,7 @@ struct Sched {
     int P2 = HS_PB;
     while (P2 < maxni) P2 *= 2;
     lu_rec(0, P2);
+    if (sn && P2 < 256) launch_inv256<T>(sn, nbatch, maxni, s, 0);  // fronts narrower than one 256-block
     if (maxnb > 0) {
       laswp(HS_MAT_UR, 0, HS_BIG, 0, P2);
       trsm_rec(HS_MAT_UR, 0, P2, 0, HS_BIG);

@@ -62,6 +62,31 @@ __device__ inline bool resolve_op(const NodeDesc<T>* pn, const GemmOp& op, GemmP
   mat_of(pn, op.bmat, bp, ldb, brows, bcols);
   const int ni = pn->ni, ldl = pn->ldl;
   T* const LF = pn->LF;
+  if (op.ainv >= 3) {
+    // 256-row TRSM base case X[r0:r0+256, c0:c1) <- inv256 * X, in place, as two half products that never read a row
+    // another workgroup may already have overwritten (each has one tile row and reads all of K before its stores):
+    //   lower (L): 3 = rows 128.. <- inv[128:256, 0:256] * X[0:256]   (first),  4 = rows 0..127 <- inv[0:128, 0:128] * X[0:128]
+    //   upper (U): 5 = rows 0..127 <- inv[0:128, 0:256] * X[0:256]    (first),  6 = rows 128.. <- inv[128:256, 128:256] * X[128:256]
+    const int wl = min(256, ni - op.r0);
+    const int N = min(op.c1, ccols) - op.c0;
+    if (wl <= 0 || N <= 0) return false;
+    const bool up = op.ainv >= 5;
+    const T* inv = (up ? pn->inv256U : pn->inv256L) + (size_t)(op.r0 / 256) * 65536;
+    const bool second_half_rows = (op.ainv == 3 || op.ainv == 6);  // output rows 128..
+    const bool full_k = (op.ainv == 3 || op.ainv == 5);
+    const int ro = second_half_rows ? 128 : 0;
+    const int M = min(128, wl - ro);
+    if (M <= 0) return false;
+    const int ko = (op.ainv == 6) ? 128 : 0;
+    const int K = full_k ? wl : (op.ainv == 4 ? min(128, wl) : wl - 128);
+    if (K <= 0) return false;
+    p.A = inv + ro + (size_t)ko * 256;
+    p.B = cp + (size_t)(op.r0 + ko) + (size_t)op.c0 * ldc;
+    p.C = cp + (size_t)(op.r0 + ro) + (size_t)op.c0 * ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = 256; p.ldb = ldc; p.ldc = ldc;
+    return true;
+  }
   if (op.ainv) {  // X[r0:r0+w, c0:c1) <- inv(L11[r0/32]) * X, in place (one tile row, all of K is read before the stores)
     const int w = min(HS_PB, ni - op.r0);
     const int N = min(op.c1, ccols) - op.c0;

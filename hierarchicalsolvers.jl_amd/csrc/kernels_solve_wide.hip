@@ -16,13 +16,13 @@
 // inverses of the 256 x 256 diagonal blocks.  grid.x = (256-block, block column j of it), grid.y = front, grid.z = L / U
 // ------------------------------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restrict__ nodes) {
+__global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restrict__ nodes, int first_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* X = reinterpret_cast<T*>(smem_raw);   // 8 blocks of 32 x 32 (column-major): X_kj of the current block column
   T* S = X + 8 * HS_PB * HS_PB;            // 32 x 32 accumulator
   const SolveNode<T> nd = nodes[blockIdx.y];
   const int upper = blockIdx.z;
-  const int b256 = blockIdx.x >> 3, jc = blockIdx.x & 7;
+  const int b256 = first_block + (blockIdx.x >> 3), jc = blockIdx.x & 7;
   const int c0 = b256 * HS_SW;
   if (c0 >= nd.ni) return;
   const int wl = min(HS_SW, nd.ni - c0);
@@ -161,16 +161,18 @@ __global__ __launch_bounds__(256) void bwd_wide_kernel(const SolveNode<T>* __res
 }
 
 template <class T>
-void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s) {
+void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s, int only_block) {
   if (nbatch <= 0 || maxni <= 0) return;
-  const int nb256 = (maxni + HS_SW - 1) / HS_SW;
+  const int first = only_block >= 0 ? only_block : 0;
+  const int nb256 = only_block >= 0 ? 1 : (maxni + HS_SW - 1) / HS_SW;
+  if (first * HS_SW >= maxni) return;
   constexpr int lds_bytes = (int)(sizeof(T) * 9 * HS_PB * HS_PB);
   static bool attr_set = false;
   if (!attr_set) {  // 72 KiB (double) / 144 KiB (complex) of LDS per workgroup needs the opt-in
     (void)hipFuncSetAttribute((const void*)inv256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL(inv256_kernel<T>, dim3(nb256 * 8, nbatch, 2), dim3(256), lds_bytes, s, dn);
+  hipLaunchKernelGGL(inv256_kernel<T>, dim3(nb256 * 8, nbatch, 2), dim3(256), lds_bytes, s, dn, first);
 }
 template <class T>
 void launch_fwd_wide(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w, T* y, T* b, hipStream_t s) {
@@ -188,8 +190,8 @@ void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hi
 }
 int hs_solve_wide_cols() { return HS_SW; }
 
-template void launch_inv256<double>(const SolveNode<double>*, int, int, hipStream_t);
-template void launch_inv256<cplx>(const SolveNode<cplx>*, int, int, hipStream_t);
+template void launch_inv256<double>(const SolveNode<double>*, int, int, hipStream_t, int);
+template void launch_inv256<cplx>(const SolveNode<cplx>*, int, int, hipStream_t, int);
 template void launch_fwd_wide<double>(const SolveNode<double>*, int, int, int, double*, double*, double*, hipStream_t);
 template void launch_fwd_wide<cplx>(const SolveNode<cplx>*, int, int, int, cplx*, cplx*, cplx*, hipStream_t);
 template void launch_bwd_wide<double>(const SolveNode<double>*, int, int, double*, double*, hipStream_t);
