@@ -582,6 +582,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     HS_HIP(hipEventCreate(&h->ev1));
     dmalloc(&h->d_fac, fac * sizeof(T), "the factors (LF/UR)");
     dmalloc(&h->d_inv, inv * sizeof(T), "the inverse diagonal blocks");
+    HS_HIP(hipMemset(h->d_inv, 0, inv * sizeof(T)));  // identity padding / unwritten corners must read as zero
     dmalloc(&h->d_sb, sb_total * sizeof(T), "the Schur-complement scratch");
     dmalloc((void**)&h->d_int, ints * sizeof(int), "index lists");
     const size_t tmpi_total = tmpi + (size_t)h->nnodes + 2 * (size_t)n;

@@ -218,7 +218,7 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
       for (int i = 0; i < count; ++i) {
         LowRank<T>* lrL = LL[i];
         if (lrL->r > 0) dmalloc((void**)&ZLo[i], ((size_t)lrL->ldz * hd[i].ni + 32) * sizeof(T), "Z_L*U^-1");
-        rj[i] = RtrsmJob<T>{lrL->Z, lrL->ldz, ZLo[i], lrL->ldz, hd[i].LF, hd[i].ldl, hd[i].invU, hd[i].ni, lrL->r};
+        rj[i] = RtrsmJob<T>{lrL->Z, lrL->ldz, ZLo[i], lrL->ldz, hd[i].LF, hd[i].ldl, hd[i].invU, hd[i].ni, lrL->r, hd[i].inv256U};
       }
       void* dp = nullptr;
       int e = rtrsm_upper_batch<T>(rj.data(), count, s, &dp);

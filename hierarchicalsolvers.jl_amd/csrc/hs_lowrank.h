@@ -44,6 +44,7 @@ struct RtrsmJob {
   int ldl;
   const T* invU;  // inverted 32x32 diagonal blocks of U
   int n, r;
+  const T* inv256U;  // inverted 256x256 diagonal blocks of U (ld 256), or null: the base case is then 32 columns
 };
 template <class T>
 int rtrsm_upper_batch(const RtrsmJob<T>* jobs, int nj, hipStream_t s, void** dprobs_out);

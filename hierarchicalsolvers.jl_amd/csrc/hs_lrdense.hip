@@ -132,6 +132,24 @@ int rtrsm_upper_batch(const RtrsmJob<T>* jobs, int nj, hipStream_t s, void** dpr
     static void run(int c0, int c1, const RtrsmJob<T>* jobs, int nj, int maxn, std::vector<GemmProb<T>>& probs, std::vector<char>& minus, std::vector<int>& stepN,
                     const GemmProb<T>& empty) {
       if (c0 >= maxn) return;
+      bool wide = (c1 - c0 == 256);
+      for (int a = 0; a < nj && wide; ++a) wide = jobs[a].inv256U != nullptr;
+      if (wide) {  // 256-column base case: one product with the stored inverse of the 256 x 256 diagonal block
+        int mx = 0;
+        for (int a = 0; a < nj; ++a) {
+          const RtrsmJob<T>& J = jobs[a];
+          const int w = std::min(256, J.n - c0);
+          if (J.r <= 0 || w <= 0) {
+            probs.push_back(empty);
+            continue;
+          }
+          probs.push_back({J.X + (size_t)c0 * J.ldx, J.inv256U + (size_t)(c0 / 256) * 65536, J.Xout + (size_t)c0 * J.ldo, J.r, w, w, J.ldx, 256, J.ldo});
+          mx = std::max(mx, w);
+        }
+        minus.push_back(0);
+        stepN.push_back(mx);
+        return;
+      }
       if (c1 - c0 == HS_PB) {
         int mx = 0;
         for (int a = 0; a < nj; ++a) {

@@ -77,12 +77,13 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
     }
     __syncthreads();
   }
-  // write the block column: rows [32i, 32i+32) x columns [32jc, 32jc+32) for the blocks that exist
+  // write the WHOLE block column (256 rows x 32 columns): the blocks of the triangle, zeros elsewhere -- the TRSM base
+  // case multiplies by the full 256 x 256 block (GemmOp::ainv 3..6)
   const int ilo = upper ? 0 : jc, ihi = upper ? jc : nsb - 1;
-  for (int i = ilo; i <= ihi; ++i)
+  for (int i = 0; i < HS_SW / HS_PB; ++i)
     for (int e = t; e < HS_PB * HS_PB; e += 256) {
       const int a = e & 31, b = e >> 5;
-      out[(size_t)(i * HS_PB + a) + (size_t)(jc * HS_PB + b) * HS_SW] = X[i * 1024 + e];
+      out[(size_t)(i * HS_PB + a) + (size_t)(jc * HS_PB + b) * HS_SW] = (i >= ilo && i <= ihi) ? X[i * 1024 + e] : Scal<T>::zero();
     }
 }
 
