@@ -441,16 +441,52 @@ __global__ __launch_bounds__(256) void laswp_kernel(const NodeDesc<T>* __restric
   mat_of(nodes + blockIdx.y, mat, p, ld, rows, cols);
   c1 = min(c1, cols);
   k1 = min(k1, nd.ni);
-  const int c = c0 + blockIdx.x * 256 + threadIdx.x;
-  if (c >= c1 || k0 >= k1) return;
-  T* col = p + (size_t)c * ld;
-  for (int k = k0; k < k1; ++k) {
-    int pv = nd.ipiv[k];
-    if (pv != k) {
-      T tmp = col[k];
-      col[k] = col[pv];
-      col[pv] = tmp;
+  if (c0 + (int)blockIdx.x * 256 >= c1 || k0 >= k1) return;  // workgroup-uniform
+  const int t = threadIdx.x;
+  const int c = c0 + blockIdx.x * 256 + t;
+  T* col = p + (size_t)min(c, c1 - 1) * ld;
+  // Most pivots of a diagonally dominant front stay where they are: the workgroup first compacts the real swaps of up to
+  // 1024 pivots (in order) into LDS, then every thread applies only those to its column.  The previous version walked all
+  // k1-k0 pivots per column even when none moved (74 ms of the 32,768 root front).
+  __shared__ int s_k[1024], s_p[1024];
+  __shared__ int s_cnt[256];
+  for (int kc = k0; kc < k1; kc += 1024) {
+    const int kb = kc + 4 * t;  // this thread's four consecutive pivots
+    int pv[4], n = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = kb + u;
+      pv[u] = (k < k1) ? nd.ipiv[k] : k;
+      n += (pv[u] != k);
     }
+    s_cnt[t] = n;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // inclusive scan of the counts
+      const int v = (t >= off) ? s_cnt[t - off] : 0;
+      __syncthreads();
+      s_cnt[t] += v;
+      __syncthreads();
+    }
+    const int total = s_cnt[255];
+    int pos = s_cnt[t] - n;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pv[u] != kb + u) {
+        s_k[pos] = kb + u;
+        s_p[pos] = pv[u];
+        ++pos;
+      }
+    }
+    __syncthreads();
+    if (c < c1) {
+      for (int q = 0; q < total; ++q) {
+        const int k = s_k[q], pq = s_p[q];
+        const T tmp = col[k];
+        col[k] = col[pq];
+        col[pq] = tmp;
+      }
+    }
+    __syncthreads();
   }
 }
 
