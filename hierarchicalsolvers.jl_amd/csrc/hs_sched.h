@@ -332,7 +332,7 @@ struct Sched {
   }
   void factor_fronts() {
     if (maxni <= 0) return;
-    static const int la_min = env_int("HS_LA_MIN", 6144), la_nb = env_int("HS_LA_NB", 1024);
+    static const int la_min = env_int("HS_LA_MIN", 1536), la_nb = env_int("HS_LA_NB", 1024);
     if (s2 && la_nb >= HS_PB && (la_nb & (la_nb - 1)) == 0 && maxni >= la_min && maxni > la_nb) {
       factor_fronts_lookahead(la_nb);
       return;
