@@ -167,6 +167,8 @@ struct hs_handle {
   int* d_int = nullptr;   // fidx, ipiv, rperm, cmap
   int* d_tmpi = nullptr;  // cand, pivlist, info[nnodes], own[n], pos[n]
   int* d_info = nullptr;
+  int* d_growth = nullptr;
+  bool optimistic = true;   // HS_OPTIMISTIC=0 turns it off; a level that had to be redone turns it off for the rest of the handle's life
   int* d_own = nullptr;
   int* d_pos = nullptr;
   int64_t* d_colptr = nullptr;
@@ -585,11 +587,12 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     HS_HIP(hipMemset(h->d_inv, 0, inv * sizeof(T)));  // identity padding / unwritten corners must read as zero
     dmalloc(&h->d_sb, sb_total * sizeof(T), "the Schur-complement scratch");
     dmalloc((void**)&h->d_int, ints * sizeof(int), "index lists");
-    const size_t tmpi_total = tmpi + (size_t)h->nnodes + 2 * (size_t)n;
+    const size_t tmpi_total = tmpi + 2 * (size_t)h->nnodes + 2 * (size_t)n;
     dmalloc((void**)&h->d_tmpi, tmpi_total * sizeof(int), "pivoting scratch");
     HS_HIP(hipMemset(h->d_tmpi, 0, tmpi_total * sizeof(int)));
     h->d_info = h->d_tmpi + tmpi;
-    h->d_own = h->d_info + h->nnodes;
+    h->d_growth = h->d_info + h->nnodes;  // optimistic-pivoting flags, one per front
+    h->d_own = h->d_growth + h->nnodes;
     h->d_pos = h->d_own + n;
     T* dfac = (T*)h->d_fac;
     T* dinv = (T*)h->d_inv;
@@ -677,6 +680,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           d.cand1 = d.cand0 + x.ncand;
           d.pivlist = d.cand1 + x.ncand;
           d.info = h->d_info + id;
+          d.growth = h->d_growth + id;
           d.fidx = dint + x.off_fidx;
           d.ni = x.ni; d.nb = x.nb; d.m = x.m;
           d.ldl = x.ldl; d.ldu = x.ldu; d.lds = x.lds;
@@ -793,6 +797,12 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     const int nb_ = (int)L.mine.size();
     static const bool progress = getenv("HS_PROGRESS") != nullptr;  // one line per level as it is enqueued (long profiler runs)
     if (progress) fprintf(stderr, "[hs] enqueue level %d (%d fronts)\n", lv, nb_);
+    // Optimistic pivoting (Sched::optimistic): the dense fronts of the level are first eliminated with every panel
+    // pivoting among its own 32 rows; if any front raised its growth flag the level is assembled again and eliminated with
+    // tournament pivoting, and the handle stops trying (a matrix that needs real pivoting needs it everywhere).
+    static const bool opt_env = !(getenv("HS_OPTIMISTIC") && getenv("HS_OPTIMISTIC")[0] == '0');
+    const bool try_opt = opt_env && h->optimistic && L.ndense > 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
     h->prof.tag = lv;
     hipEvent_t ea = h->prof.begin(s);
     // zero-fill this level's fronts: LF/UR are contiguous per level; SB of the owned fronts only
@@ -816,7 +826,19 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     if (L.ndense > 0) {
       Sched<T> sch{dn, L.ndense, L.dmaxni, L.dmaxnb, L.dmaxm, s, &h->prof, L.h_ni.data(), L.h_nb.data(), h->stream2, 0, h->stream_la, h->stream2m};
       sch.sn = (const SolveNode<T>*)h->d_solve + L.desc_off;  // lu_rec leaves the 256x256 inverse diagonal blocks behind
+      sch.optimistic = try_opt && attempt == 0;
       sch.factor_fronts();
+    }
+      if (!(try_opt && attempt == 0)) break;
+      std::vector<int> gr(h->nnodes);
+      HS_HIP(hipMemcpyAsync(gr.data(), h->d_growth, sizeof(int) * h->nnodes, hipMemcpyDeviceToHost, s));
+      HS_HIP(hipStreamSynchronize(s));
+      static const bool force_redo = getenv("HS_OPTIMISTIC_FORCE_REDO") != nullptr;  // tests: exercise the redo machinery
+      bool redo = force_redo;
+      for (int k = 0; k < L.ndense; ++k) redo = redo || gr[L.mine[k]] != 0;
+      if (!redo) break;
+      h->optimistic = false;
+      if (h->opts.verbose) fprintf(stderr, "[hs] level %d: a pivot outside the diagonal block was needed; redoing the level with tournament pivoting\n", lv);
     }
     if (nb_ > L.ndense) factor_compressed_level<T>(h, L.mine.data() + L.ndense, nb_ - L.ndense, dn + L.ndense, (const SolveNode<T>*)h->d_solve + L.desc_off + L.ndense);  // hs_compress.h
     static const bool lvl_env = getenv("HS_VERBOSE_LEVELS") != nullptr;

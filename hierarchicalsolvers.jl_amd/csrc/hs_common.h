@@ -17,6 +17,7 @@
 #define HS_PB 32          // panel width (columns factored per tournament-pivoting step)
 #define HS_CHUNK 256      // rows per tournament chunk (= threads per workgroup)
 #define HS_BIG (1 << 30)
+#define HS_GROWTH_MAX 4.0  // optimistic diagonal-block pivoting is accepted while every multiplier |l_ij| <= this
 
 struct cplx {
   double re, im;
@@ -78,6 +79,8 @@ struct NodeDesc {
   int* cand1;
   int* pivlist;  // HS_PB selected rows of the current panel
   int* info;     // 0 = ok, else 1 + first column with an exactly zero pivot (SingularException)
+  int* growth;   // optimistic pivoting (panel_pivot, fuse & 4): set to 1 when a multiplier exceeded HS_GROWTH_MAX or a block was
+                 // singular on its own rows -- the level is then redone with tournament pivoting; may be null
   const int* fidx;  // m global DOF ids (0-based), front order [int; bnd]
   int ni, nb, m;
   int ldl, ldu, lds;

@@ -81,6 +81,8 @@ struct Sched {
   const SolveNode<T>* sn = nullptr;  // solve descriptors of the same batch: lu_rec leaves the inverses of the 256x256 diagonal
                                      // blocks of L and U behind (TRSM base case of 256 rows; ldiv! sweeps); null = 32-row base only
   bool wide = false;                 // the descriptors carry valid inv256L / inv256U for the rows being solved
+  bool optimistic = false;           // no tournament: every panel pivots among its own 32 rows, panel_l21 checks the multipliers
+                                     // (NodeDesc::growth); the caller redoes the batch with the tournament if the flag went up
 
   // HS_DEBUG_SYNC=1: synchronise after every launch and report the first failing one (diagnostics only)
   void dbg(const char* what, int a = 0, int b = 0, int c = 0, int d = 0) {
@@ -128,7 +130,9 @@ struct Sched {
     // HS_TOUR_BIG=1 selects the 1024-row-chunk kernel (fewer stages, but a workgroup needs a whole idle CU)
     static const int big = env_int("HS_TOUR_BIG", 0);
     hipEvent_t e0 = pf->begin(s);
-    if (big) {
+    if (optimistic) {
+      fuse |= 4;
+    } else if (big) {
       const int BR = hs_tour_block_rows(sizeof(T) == 16);
       int cnt = (maxpiv > 0 ? maxpiv : maxni) - c0, nblk = (cnt + BR - 1) / BR;
       for (int stage = 0;; ++stage) {

@@ -109,6 +109,7 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
     d.cand1 = d.cand0 + ncand;
     d.pivlist = d.cand1 + ncand;
     d.info = d.pivlist + HS_PB;
+    d.growth = d.info;  // HS_HOOK_OPTIMISTIC=1: the growth flag of optimistic pivoting comes back through `info` as -1
     d.ni = (int)ni; d.nb = (int)nb; d.m = m;
     d.ldl = ldl; d.ldu = ldu; d.lds = lds;
     d.ni1 = (int)ni; d.nb1 = (int)nb; d.isleaf = 1; d.node = (int)k;
@@ -131,6 +132,8 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
   launch_init_fronts<T>(dn, (int)count, (int)ni, s_main);
   Sched<T> sch{dn, (int)count, (int)ni, (int)nb, m, s_main, &prof, nullptr, nullptr, s_side, 0, s_la, s_sidem};
   const auto h0 = std::chrono::steady_clock::now();
+  const bool hook_opt = getenv("HS_HOOK_OPTIMISTIC") != nullptr;
+  sch.optimistic = hook_opt;
   sch.factor_fronts();
   CK(hipEventRecord(e1, s_main));
   if (getenv("HS_HOOK_VERBOSE"))
@@ -151,7 +154,7 @@ static int front_hook(int64_t count, int64_t ni, int64_t nb, const T* F, T* outL
       for (int64_t i = 0; i < ni; ++i) out_rperm[ni * k + i] = ip[i];
     int inf = 0;
     CK(hipMemcpy(&inf, d.info, sizeof(int), hipMemcpyDeviceToHost));
-    if (info) info[k] = inf;
+    if (info) info[k] = (hook_opt && inf != 0) ? -1 : inf;
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

@@ -41,7 +41,10 @@ template <class T>
 __global__ __launch_bounds__(256) void init_fronts_kernel(const NodeDesc<T>* __restrict__ nodes) {
   const NodeDesc<T> nd = nodes[blockIdx.y];
   int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) *nd.info = 0;
+  if (i == 0) {
+    *nd.info = 0;
+    if (nd.growth) *nd.growth = 0;
+  }
   if (i < nd.pivrows) nd.rperm[i] = i;
 }
 

@@ -163,7 +163,43 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
   }
   __syncthreads();
   __shared__ int s_pl[HS_PB];
-  if (t < HS_PB) s_pl[t] = (t < w) ? nd.pivlist[t] : -1;
+  const bool optimistic = (fuse & 4) != 0;
+  if (!optimistic) {
+    if (t < HS_PB) s_pl[t] = (t < w) ? nd.pivlist[t] : -1;
+  } else if (t < 64) {
+    // fuse & 4: OPTIMISTIC pivoting -- no tournament ran; partial pivoting among the block's own w rows decides the order
+    // (one wave, lane i = row c0+i in registers).  panel_l21 checks the multipliers of the rows below against
+    // HS_GROWTH_MAX; a violation, or a block that is singular on its own rows, raises nd.growth and the level is redone
+    // with the tournament.  For the diagonally dominant fronts of elliptic problems the check never fires and the chain of
+    // a panel step shrinks from (rounds + 2) dependent kernels to 2.
+    const int i = t & 31;
+    T x[HS_PB];
+    bool alive = (t < w);
+#pragma clang loop unroll(full)
+    for (int j = 0; j < HS_PB; ++j) x[j] = (alive && j < w) ? nd.LF[(size_t)(c0 + i) + (size_t)(c0 + j) * nd.ldl] : Scal<T>::zero();
+    bool bad = false;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < HS_PB; ++k) {
+      unsigned long long key = 0;
+      if (alive && k < w) key = ((unsigned long long)__double_as_longlong(Scal<T>::abs1(x[k])) & ~0xffull) | (unsigned long long)(255 - t);
+      const unsigned long long best = wave_max_u64(key);
+      int win = -1;
+      if (k < w && (best >> 8) != 0) win = 255 - (int)(best & 0xff);
+      if (k < w && win < 0) bad = true;  // nothing left in this column on the block's rows
+      if (t == 0) s_pl[k] = (k < w) ? (win >= 0 ? c0 + win : -1) : -1;
+      if (win >= 0) {
+        const T pk = lane_bcast(x[k], win);
+        const T rp = Scal<T>::one() / pk;
+        T l = Scal<T>::zero();
+        if (alive && t != win) l = x[k] * rp;
+        if (t == win) alive = false;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j)
+          if (j > k) x[j] = Scal<T>::fnma(l, lane_bcast(x[j], win), x[j]);
+      }
+    }
+    if (bad && t == 0 && nd.growth) *nd.growth = 1;
+  }
   __syncthreads();
   if (t == 0) {
     // winners (rows by their position at panel start, in elimination order) -> LAPACK-style swaps.
@@ -188,7 +224,7 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
         s_where[q - c0] = p;
       }
     }
-    if (first_bad) {
+    if (first_bad && !optimistic) {  // optimistic: the growth flag is already up, the redo decides about singularity
       int old = *nd.info;
       if (old == 0 || old > first_bad) *nd.info = first_bad;
     }
@@ -253,8 +289,12 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
       const bool zero_piv = (Scal<T>::abs1(piv) == 0.0);
       if (t < HS_PB && t > k && !zero_piv) s_a[t][k] = s_a[t][k] / piv;
       if (zero_piv && t == 0 && k < w) {
-        int old = *nd.info;
-        if (old == 0 || old > c0 + k + 1) *nd.info = c0 + k + 1;
+        if (optimistic) {
+          if (nd.growth) *nd.growth = 1;
+        } else {
+          int old = *nd.info;
+          if (old == 0 || old > c0 + k + 1) *nd.info = c0 + k + 1;
+        }
       }
       __syncthreads();
       if (!zero_piv) {
@@ -313,8 +353,12 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
       }
     }
     if (bad && t == 0) {
-      int old = *nd.info;
-      if (old == 0 || old > bad) *nd.info = bad;
+      if (optimistic) {
+        if (nd.growth) *nd.growth = 1;
+      } else {
+        int old = *nd.info;
+        if (old == 0 || old > bad) *nd.info = bad;
+      }
     }
     if (t < HS_PB) {
 #pragma clang loop unroll(full)
@@ -406,6 +450,7 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
 #pragma unroll
   for (int j = 0; j < HS_PB; ++j) a[j] = (j < w) ? base[(size_t)j * nd.ldl] : Scal<T>::zero();
   T l[HS_PB];
+  double lmax = 0.0;
 #pragma unroll
   for (int j = 0; j < HS_PB; ++j) {
     T s = Scal<T>::zero();
@@ -413,8 +458,12 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
     for (int i = 0; i < HS_PB; ++i)
       if (i <= j) s = Scal<T>::fma(a[i], s_iu[i + j * HS_PB], s);
     l[j] = s;
+    lmax = fmax(lmax, Scal<T>::abs1(s));
     if (j < w) base[(size_t)j * nd.ldl] = s;
   }
+  // fuse & 4: optimistic pivoting -- a row that partial pivoting could have picked (row < pivrows) must not need a
+  // multiplier beyond HS_GROWTH_MAX; otherwise the level is redone with tournament pivoting (NaN counts as a violation)
+  if ((fuse & 4) && row < nd.pivrows && !(lmax <= HS_GROWTH_MAX) && nd.growth) *nd.growth = 1;
   if (w2 > 0) {
     T* nxt = base + (size_t)HS_PB * nd.ldl;
 #pragma unroll 4

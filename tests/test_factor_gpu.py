@@ -7,6 +7,8 @@ Tolerances (FP64, stated per SURVEY.md section 8(c)): the dense path is exact, s
 Pivot orders differ (tournament pivoting here, LAPACK partial pivoting in Julia/the oracle), so
 block-wise agreement is to rounding, not bitwise.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse.linalg as spla
@@ -200,3 +202,59 @@ def test_golden_fixtures_on_device(hs):
                 assert relerr(rb["L"], fx["L"][k]) < BLK_TOL, (f, k)
                 assert relerr(rb["R"], fx["R"][k]) < BLK_TOL, (f, k)
                 assert relerr(rb["S"], fx["S"][k]) < BLK_TOL, (f, k)
+
+
+def test_optimistic_pivoting_detection(hs, monkeypatch):
+    """Optimistic pivoting at the kernel level (test hook): on a diagonally dominant front the growth flag stays down
+    and the factors are exact; on a random front (partial pivoting leaves the diagonal block all the time) it goes up."""
+    import ctypes as C
+
+    from hierarchicalsolvers_jl_amd import _lib
+
+    monkeypatch.setenv("HS_HOOK_OPTIMISTIC", "1")
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    ni, nb = 200, 70
+    m = ni + nb
+    for dominant in (True, False):
+        F = np.asfortranarray(rng.standard_normal((m, m)))
+        if dominant:
+            F[np.arange(m), np.arange(m)] += 4.0 * np.sqrt(m)
+        outLF = np.zeros((m, ni), order="F")
+        outUR = np.zeros((ni, nb), order="F")
+        outSB = np.zeros((nb, nb), order="F")
+        rp = np.zeros(ni, dtype=np.int64)
+        info = np.zeros(1, dtype=np.int64)
+        ms = C.c_double(0)
+        p = lambda a: a.ctypes.data_as(_lib.p_f64)  # noqa: E731
+        _lib.check(L.hsk_front_factor_d(1, ni, nb, p(F), p(outLF), p(outUR), p(outSB), rp.ctypes.data_as(_lib.p_i64), info.ctypes.data_as(_lib.p_i64), C.byref(ms)))
+        if dominant:
+            assert info[0] == 0
+            S = F[ni:, ni:] - F[ni:, :ni] @ np.linalg.solve(F[:ni, :ni], F[:ni, ni:])
+            assert relerr(outSB, S) < 1e-11
+        else:
+            assert info[0] == -1  # a multiplier beyond the growth bound: the caller must redo with the tournament
+
+
+def test_optimistic_pivoting_redo_path():
+    """The level-redo machinery of hs_numeric_levels (assemble again, eliminate with tournament pivoting), forced through
+    HS_OPTIMISTIC_FORCE_REDO in a child process: exact solution, the handle stops trying afterwards."""
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, scipy.sparse.linalg as spla, hsamd\n"
+        "hs = hsamd.load()\n"
+        "from helpers import prepare, relerr\n"
+        "P = prepare(hs, (24, 24), kind='poisson', nmax=40, rhs='randn')\n"
+        "F = hs.factor(P['A'], P['nd'], P['nd_loc'], swlevel=0, verbose=True)\n"
+        "print('ERR', relerr(hs.ldiv(F, P['b']), spla.splu(P['A']).solve(P['b'])))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, HS_OPTIMISTIC_FORCE_REDO="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("redoing the level with tournament pivoting") == 1  # the first level only: then the handle gives up
+    err = float([ln for ln in r.stdout.splitlines() if ln.startswith("ERR")][0].split()[1])
+    assert err < 1e-10
