@@ -296,7 +296,9 @@ struct Sched {
     // two GEMM workgroups; HS_LA_GEMM_CAP of them in total, default 448 of the 512): the ~10 tiny dependent kernels of
     // each 32-column panel step then start at once instead of waiting for a GEMM workgroup to retire
     static const int cap_total = env_int("HS_LA_GEMM_CAP", 448);
-    const int gcap = (cap_total > 0 && nbatch == 1) ? cap_total : 0;  // measured: helps a lone front, hurts batches (uneven fronts)
+    // measured: helps a lone front whose panels run the tournament, hurts batches (uneven fronts) and is not needed once
+    // the panel chain is short (optimistic pivoting: 520 -> 500 ms on the 32,768 root without the cap)
+    const int gcap = (cap_total > 0 && nbatch == 1 && !optimistic) ? cap_total : 0;
     hipEvent_t ev_iter[3];
     for (auto& e : ev_iter) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     int iter = 0;
