@@ -15,3 +15,4 @@ from ._lib import DimensionMismatch, SingularException, DeviceError, Unsupported
 from . import _lib  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
 from .gmres import gmres  # noqa: F401,E402
+from . import hss  # noqa: F401,E402

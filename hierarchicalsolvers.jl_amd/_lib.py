@@ -46,6 +46,11 @@ class hs_stats(C.Structure):
     ]
 
 
+class hs_hss_options(C.Structure):
+    _fields_ = [("leafsize", i64), ("first_split", i64), ("atol", C.c_double), ("rtol", C.c_double), ("kest", i64), ("pad", i64), ("seed", i64),
+                ("level_scale", C.c_double)]
+
+
 HS_OK = 0
 HS_ERR_ARGUMENT, HS_ERR_DIMENSION, HS_ERR_TREE, HS_ERR_SINGULAR = -1, -2, -3, -4
 HS_ERR_HSS_LEAF, HS_ERR_DEVICE, HS_ERR_NOMEM, HS_ERR_UNSUPPORTED = -5, -6, -7, -8
@@ -60,6 +65,8 @@ EXPORTS = [
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned",
     "hs_symbolic_from_elimtree", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
+    "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
+    "hs_hss_node_info", "hs_hss_node_data", "hs_hss_mul", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak",
 ]
 
@@ -177,6 +184,28 @@ def lib():
     for f in (L.hsk_lowrank_d, L.hsk_lowrank_z):
         f.argtypes = [i64, i64, p_f64, C.c_double, C.c_double, i64, i64, p_i64, p_f64, p_f64, i64]
         f.restype = C.c_int
+    L.hs_hss_options_default.argtypes = [C.POINTER(hs_hss_options)]
+    L.hs_hss_options_default.restype = None
+    for f in (L.hs_hss_compress_d, L.hs_hss_compress_z):
+        f.argtypes = [i64, vp, i64, C.c_int, C.POINTER(hs_hss_options), C.POINTER(vp)]
+        f.restype = C.c_int
+    for f in (L.hs_hss_rank, L.hs_hss_size, L.hs_hss_samples, L.hs_hss_num_nodes):
+        f.argtypes = [vp]
+        f.restype = i64
+    L.hs_hss_node_info.argtypes = [vp, i64, p_i64]
+    L.hs_hss_node_info.restype = C.c_int
+    L.hs_hss_node_data.argtypes = [vp, i64, p_i64, vp, vp, vp, vp]
+    L.hs_hss_node_data.restype = C.c_int
+    L.hs_hss_mul.argtypes = [vp, vp, i64, vp, i64, i64, C.c_int]
+    L.hs_hss_mul.restype = C.c_int
+    L.hs_hss_factor.argtypes = [vp]
+    L.hs_hss_factor.restype = C.c_int
+    L.hs_hss_ldiv.argtypes = [vp, vp, i64, i64, C.c_int]
+    L.hs_hss_ldiv.restype = C.c_int
+    L.hs_hss_time.argtypes = [vp, C.c_int]
+    L.hs_hss_time.restype = C.c_double
+    L.hs_hss_free.argtypes = [vp]
+    L.hs_hss_free.restype = None
     L.hsk_mfma_f64_peak.argtypes = [C.c_int, C.c_int]
     L.hsk_mfma_f64_peak.restype = C.c_double
     _lib = L

@@ -1,0 +1,75 @@
+/*
+ * hs_hss.h -- C ABI of the device HSS module of libhs_solver (gfx950).
+ *
+ * In the reference the Schur complement `S` of a compressed front and its interior block `D = Aii` are
+ * `HssMatrix` objects of HssMatrices.jl (a dependency that is NOT part of the reference tree, Manifest.toml:263-269).
+ * These entry points are what a Julia `ccall` shim binds in place of the HssMatrices calls the hot path makes:
+ *
+ *   hs_hss_compress_{d,z}  <- compress(S[perm,perm], cl, cl; atol, rtol)              src/factorization.jl:56-57
+ *                             randcompress_adaptive(hssS, cl, cl; kest, atol, rtol)   src/factorization.jl:109-110
+ *                             with cl = bisection_cluster((n1, n); leafsize)          src/factorization.jl:56,109
+ *   hs_hss_rank            <- hssrank(F.S)                                            src/factornode.jl:53
+ *   hs_hss_mul             <- `*` of an HssMatrix with a dense block                  src/factorization.jl:242, blockmatrix.jl:97
+ *   hs_hss_factor / _ldiv  <- `\` with HssMatrix blocks inside blockfactor / blockldiv!  src/blockmatrix.jl:121-156
+ *
+ * Representation (oracle/hs_hss.py restates it on the CPU): binary cluster tree in breadth-first order (node 0 =
+ * root); every non-root node keeps ONE skeleton for rows and columns -- local positions `p` (the r skeleton
+ * positions first) and the interpolation matrix T ((m-r) x r): A(I[p_R], far) ~= T A(I[p_S], far),
+ * A(far, I[p_R]) ~= A(far, I[p_S]) T^T (plain transpose) -- leaves keep their diagonal block D, inner nodes the
+ * couplings B12 = A(sk_l, sk_r), B21 = A(sk_r, sk_l) of their children's skeletons.  hs_hss_factor eliminates the
+ * redundant positions level by level (ID-based ULV elimination, "recursive skeletonization"); hs_hss_ldiv applies
+ * the inverse.  Column-major everywhere; complex = interleaved (re, im) doubles (Julia ComplexF64).
+ * `where`: 0 = the pointers are host memory, 1 = device memory (no PCIe traffic).
+ */
+#ifndef HS_HSS_H
+#define HS_HSS_H
+#include <stdint.h>
+#include "hs_solver.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hs_hss hs_hss; /* opaque: owns the device-resident generators and factors */
+
+typedef struct hs_hss_options {
+  int64_t leafsize;    /* leaves of the cluster tree hold at most this many indices (SolverOptions.leafsize) */
+  int64_t first_split; /* > 0: the root splits at this index, bisection_cluster((n1, n)); 0: in the middle */
+  double atol, rtol;   /* an off-diagonal block is truncated at max(atol, rtol * |largest pivot of its samples|) */
+  int64_t kest;        /* initial number of samples per side; doubled until every rank <= samples - pad */
+  int64_t pad;         /* oversampling (default 8) */
+  int64_t seed;
+  double level_scale;  /* tolerances of tree level l are multiplied by level_scale^(l-1) (root = level 0): deeper levels are
+                          truncated more tightly so that their accumulated error stays below the truncation threshold of
+                          the levels above (default 0.5; 1 = the same tolerance everywhere) */
+} hs_hss_options;
+
+void hs_hss_options_default(hs_hss_options* o); /* 64, 0, 1e-6, 1e-6, 64, 8, 123, 0.5 */
+
+/* HSS form of the dense n x n matrix A (column-major, leading dimension lda). */
+int hs_hss_compress_d(int64_t n, const double* A, int64_t lda, int where, const hs_hss_options* o, hs_hss** out);
+int hs_hss_compress_z(int64_t n, const double* A, int64_t lda, int where, const hs_hss_options* o, hs_hss** out);
+
+int64_t hs_hss_rank(const hs_hss* H);      /* hssrank: largest rank of an off-diagonal block */
+int64_t hs_hss_size(const hs_hss* H);      /* n */
+int64_t hs_hss_samples(const hs_hss* H);   /* samples per side the adaptive compression ended with */
+int64_t hs_hss_num_nodes(const hs_hss* H); /* nodes of the cluster tree (breadth-first numbering) */
+/* out[0..7] = lo, hi (0-based half-open index range), left, right (-1: leaf), level, m (local size), r (rank), isleaf */
+int hs_hss_node_info(const hs_hss* H, int64_t node, int64_t out[8]);
+/* generators of one node copied to tightly packed host arrays (any pointer may be NULL):
+ * p[m] (0-based local positions, skeleton first), T ((m-r) x r), D (m x m, leaves), B12 (r_l x r_r), B21 (r_r x r_l) */
+int hs_hss_node_data(const hs_hss* H, int64_t node, int64_t* p, double* T, double* D, double* B12, double* B21);
+
+/* Y = H * X for n x nrhs blocks */
+int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where);
+/* ULV-type elimination of the HSS matrix (once), then B <- H^-1 B in place */
+int hs_hss_factor(hs_hss* H);
+int hs_hss_ldiv(hs_hss* H, double* B, int64_t ldb, int64_t nrhs, int where);
+/* wall time of the last compress / factor on the device (seconds, host clock around a synchronised stream) */
+double hs_hss_time(const hs_hss* H, int what); /* 0: compress, 1: factor */
+
+void hs_hss_free(hs_hss* H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -96,7 +96,7 @@ def test_options_mirror(hs):
 def test_library_exports_every_declared_symbol(hs):
     lib = hs._lib.lib()
     declared = set()
-    for hdr in ("hs_solver.h", "hs_kernels.h", "hs_symbolic.h"):
+    for hdr in ("hs_solver.h", "hs_kernels.h", "hs_symbolic.h", "hs_hss.h"):
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         declared |= set(re.findall(r"\b(hsk?_[a-z0-9_]+)\s*\(", txt))

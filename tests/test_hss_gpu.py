@@ -1,0 +1,124 @@
+"""GPU parity tests of the device HSS module (include/hs_hss.h) against the CPU oracle (oracle/hs_hss.py).
+
+HssMatrices.jl is absent from the reference tree: PARITY UNPINNED against the Julia package.  What is checked:
+the device generators, fed to the ORACLE's matvec / expansion / elimination, reproduce the matrix to the
+tolerance; the device product and the device solve agree with the oracle's on the same generators to round-off;
+ranks agree with the oracle's own compression of the same matrix within a small margin."""
+import numpy as np
+import pytest
+
+from oracle import hs_hss as HS
+from test_hss_oracle import kernel_matrix, schur_of_separator
+
+pytestmark = pytest.mark.gpu
+
+
+def to_oracle(Hd):
+    """Oracle `Hss` object holding the DEVICE generators."""
+    n = Hd.shape[0]
+    nodes = []
+    for i in range(Hd.num_nodes):
+        d = Hd.node(i)
+        x = HS.HssNode(d["lo"], d["hi"], d["level"])
+        x.left, x.right, x.m, x.r = d["left"], d["right"], d["m"], d["r"]
+        if i != 0:
+            x.p, x.T = d["p"].astype(np.int64), d["T"]
+        x.D, x.B12, x.B21 = d["D"], d["B12"], d["B21"]
+        nodes.append(x)
+    for i, x in enumerate(nodes):
+        for c in (x.left, x.right):
+            if c >= 0:
+                nodes[c].parent = i
+    return HS.Hss(n, nodes, Hd.dtype)
+
+
+def check_tree(Ho, n, leafsize):
+    for i, x in enumerate(Ho.nodes):
+        if x.left < 0:
+            assert x.hi - x.lo <= leafsize and x.m == x.hi - x.lo
+        else:
+            l, r = Ho.nodes[x.left], Ho.nodes[x.right]
+            assert (l.lo, r.hi, l.hi) == (x.lo, x.hi, r.lo) and x.m == l.r + r.r
+        if i:
+            assert sorted(x.p.tolist()) == list(range(x.m)) and 1 <= x.r <= x.m and x.T.shape == (x.m - x.r, x.r)
+    assert Ho.nodes[0].lo == 0 and Ho.nodes[0].hi == n
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+@pytest.mark.parametrize("n,leaf,tol", [(500, 40, 1e-4), (1200, 64, 1e-8)])
+def test_compress_mul_ldiv_against_oracle(hs, complex_, n, leaf, tol):
+    A = kernel_matrix(n, complex_)
+    Hd = hs.hss.compress(A, leafsize=leaf, atol=tol, rtol=tol, kest=32)
+    Ho = to_oracle(Hd)
+    check_tree(Ho, n, leaf)
+    Fh = HS.hss_full(Ho)
+    err = np.linalg.norm(Fh - A) / np.linalg.norm(A)
+    assert err < 100 * tol, err
+    # ranks: the oracle's own compression of the same matrix (QR-based IDs) is the yardstick
+    ro = HS.hssrank(HS.compress(A, leafsize=leaf, atol=tol, rtol=tol, kest=32, level_scale=0.5))
+    assert Hd.rank == HS.hssrank(Ho) and Hd.rank <= ro + 12, (Hd.rank, ro)
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, 3)) + (1j * rng.standard_normal((n, 3)) if complex_ else 0)
+    # product: device kernels vs the oracle's matvec on the same generators (round-off only)
+    Yd = Hd @ X
+    Yo = HS.hss_matvec(Ho, X)
+    assert np.linalg.norm(Yd - Yo) <= 1e-12 * np.linalg.norm(Fh) * np.linalg.norm(X)
+    y1 = Hd @ X[:, 0]
+    assert y1.shape == (n,) and np.allclose(y1, Yd[:, 0])
+    # elimination + solve: inverse of the HSS matrix (not of A)
+    Zd = Hd.ldiv(X)
+    Zo = HS.rs_solve(HS.rs_factor(Ho), X)
+    ref = np.linalg.solve(Fh, X)
+    assert np.linalg.norm(Zo - ref) / np.linalg.norm(ref) < 1e-9
+    assert np.linalg.norm(Zd - ref) / np.linalg.norm(ref) < 1e-9
+    assert np.linalg.norm(Zd - np.linalg.solve(A, X)) / np.linalg.norm(ref) < 1e4 * tol
+    assert Hd.times()["compress_s"] > 0 and Hd.times()["factor_s"] > 0
+
+
+def test_first_split_single_leaf_and_adaptivity(hs):
+    A = kernel_matrix(300)
+    H = hs.hss.compress(A, hs.hss.bisection_cluster((100, 300), leafsize=50), atol=1e-8, rtol=1e-8)
+    Ho = to_oracle(H)
+    assert (Ho.nodes[1].lo, Ho.nodes[1].hi, Ho.nodes[2].hi) == (0, 100, 300)
+    assert np.linalg.norm(HS.hss_full(Ho) - A) / np.linalg.norm(A) < 1e-6
+    # one leaf: H = D
+    B = kernel_matrix(48)
+    H1 = hs.hss.compress(B, leafsize=64)
+    assert H1.num_nodes == 1 and H1.rank == 0
+    x = np.arange(48.0)
+    assert np.allclose(H1 @ x, B @ x) and np.allclose(H1.ldiv(x), np.linalg.solve(B, x))
+    # 8 samples cannot carry the ranks at 1e-10: the sample count must have grown
+    H2 = hs.hss.randcompress_adaptive(kernel_matrix(256, seed=3), leafsize=32, atol=1e-10, rtol=1e-10, kest=8)
+    assert H2.samples > 8
+    assert np.linalg.norm(H2.full() - kernel_matrix(256, seed=3)) / np.linalg.norm(kernel_matrix(256, seed=3)) < 1e-7
+
+
+def test_schur_complement_of_a_separator(hs):
+    """What `S` of a compressed front is (factorization.jl:56-57,109-110): compressible at the front tolerances, and the
+    HSS solve is a good preconditioner-quality inverse."""
+    S = schur_of_separator(32)
+    for tol, rmax in ((1e-2, 16), (1e-6, 32)):
+        H = hs.hss.compress(S, leafsize=8, atol=tol, rtol=tol, kest=16)
+        assert np.linalg.norm(H.full() - S) / np.linalg.norm(S) < 100 * tol
+        assert H.rank <= rmax
+        b = np.ones(S.shape[0])
+        x = H.ldiv(b)
+        assert np.linalg.norm(S @ x - b) / np.linalg.norm(b) < 1e3 * tol
+
+
+def test_large_block_timing(hs):
+    """A 4096 x 4096 kernel block: records compress / factor times (printed with -s), solution checked."""
+    n = 4096
+    A = kernel_matrix(n)
+    H = hs.hss.compress(A, leafsize=128, atol=1e-6, rtol=1e-6, kest=64)
+    b = np.ones(n)
+    x = H.ldiv(b)
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-3
+    print("hss 4096: rank", H.rank, "samples", H.samples, H.times())
+
+
+def test_errors(hs):
+    with pytest.raises(hs.DimensionMismatch):
+        hs.hss.compress(np.zeros((3, 4)))
+    with pytest.raises(ValueError):
+        hs.hss.compress(np.eye(8), leafsize=0)
