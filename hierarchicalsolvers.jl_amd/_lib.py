@@ -23,7 +23,7 @@ class hs_options(C.Structure):
     _fields_ = [
         ("swlevel", i64), ("swsize", i64), ("atol", C.c_double), ("rtol", C.c_double), ("c_tol", C.c_double),
         ("leafsize", i64), ("kest", i64), ("stepsize", i64), ("verbose", C.c_uint8),
-        ("keep_schur", C.c_uint8), ("profile", C.c_uint8), ("split", C.c_uint8), ("reserved", C.c_uint8 * 4), ("seed", i64),
+        ("keep_schur", C.c_uint8), ("profile", C.c_uint8), ("split", C.c_uint8), ("hss_d", C.c_uint8), ("reserved", C.c_uint8 * 3), ("seed", i64),
     ]
 
 
@@ -65,7 +65,7 @@ EXPORTS = [
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned",
     "hs_symbolic_from_elimtree", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
-    "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
+    "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_mul", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak",
 ]
@@ -189,9 +189,14 @@ def lib():
     for f in (L.hs_hss_compress_d, L.hs_hss_compress_z):
         f.argtypes = [i64, vp, i64, C.c_int, C.POINTER(hs_hss_options), C.POINTER(vp)]
         f.restype = C.c_int
+    for f in (L.hs_hss_compress_ex_d, L.hs_hss_compress_ex_z):
+        f.argtypes = [i64, vp, i64, C.c_int, p_i64, C.POINTER(hs_hss_options), vp, C.POINTER(vp)]
+        f.restype = C.c_int
     for f in (L.hs_hss_rank, L.hs_hss_size, L.hs_hss_samples, L.hs_hss_num_nodes):
         f.argtypes = [vp]
         f.restype = i64
+    L.hs_hss_set_stream.argtypes = [vp, vp]
+    L.hs_hss_set_stream.restype = C.c_int
     L.hs_hss_node_info.argtypes = [vp, i64, p_i64]
     L.hs_hss_node_info.restype = C.c_int
     L.hs_hss_node_data.argtypes = [vp, i64, p_i64, vp, vp, vp, vp]

@@ -124,6 +124,14 @@ struct NodeH {
   int user = -1;                 // user (post-order) node id this internal node belongs to
   int oni = 0, oni1 = 0, onb1 = 0;  // split points of the front the children address (= ni, ni1, nb1 unless kind 1)
   long long off_spos = -1;          // kind 1 with re-ordered interior: int offset of the slice-order -> original-position table
+  // hs_hssfront.h: D = Aii kept as an HSS matrix (hs_options.hss_d)
+  bool hssd = false;
+  void* hss = nullptr;        // hs_hss*
+  void* hW = nullptr;         // Aii^-1 * C_R (ni x rank(R), leading dimension hldw)
+  int hldw = 0;
+  void* ht = nullptr;         // ni entries: D^-1 rhs[int] between the two sweeps of ldiv!
+  int last_k = 0;             // samples the previous compression of D ended with
+  std::vector<int64_t> ilv;   // interleaved order of the interior positions (empty: as assembled)
 };
 
 struct LevelH {
@@ -136,6 +144,7 @@ struct LevelH {
   size_t sc_off = 0, sc_cnt = 0;    // ScatterDesc range
   std::vector<int> h_ni, h_nb;
   int ndense = 0;                          // the first ndense entries of `mine` are dense fronts (one batch), the rest compressed
+  int nplain = 0;                          // of those, the first nplain keep a dense LU of D, the others an HSS form (hs_hssfront.h)
   int dmaxni = 0, dmaxnb = 0, dmaxm = 0;   // extents of the dense batch
 };
 
@@ -205,8 +214,10 @@ static inline int rup(int x, int a) { return (x + a - 1) / a * a; }
 static inline size_t rups(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static void free_lowrank_any(hs_handle* h);
+static void free_hss_any(hs_handle* h);
 static void free_handle(hs_handle* h) {
   if (!h) return;
+  free_hss_any(h);
   free_lowrank_any(h);
   void* ptrs[] = {h->d_fac,   h->d_inv, h->d_sb,    h->d_int, h->d_tmpi, h->d_colptr, h->d_rowval, h->d_nz,
                   h->d_nodes, h->d_sc,  h->d_solve, h->d_w1,  h->d_w2,   h->d_part,   h->d_b};
@@ -410,6 +421,7 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr, const SplitTr
 
 static void dmalloc(void** p, size_t bytes, const char* what);
 #include "hs_compress.h"
+#include "hs_hssfront.h"
 
 static double front_flops(double ni, double nb) { return (2.0 / 3.0) * ni * ni * ni + 2.0 * ni * ni * nb + 2.0 * ni * nb * nb; }
 
@@ -472,12 +484,26 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     int64_t swlevel = opts.swlevel < 0 ? std::max<int64_t>(nlev + opts.swlevel, 0) : opts.swlevel;
     for (int i = 0; i < h->nreal; ++i)  // compression_flag of factorization.jl:15 (hs_compress.h); levels of the USER's tree when fronts are split
       N[i].compressed = split.active ? (split.cflag[i] != 0) : hs_compression_flag(N[i].level, N[i].ni, N[i].nb, N[i].leaf, swlevel, opts.swsize);
+    if (opts.hss_d > 0 && nranks == 1 && !split.active && swlevel > 0 && !plan_only) {
+      // fronts of the compressed levels with a large interior block keep D as an HSS matrix (hs_hssfront.h); the root too
+      std::vector<int> where((size_t)n, -1);
+      for (int i = 0; i < h->nreal; ++i) {
+        NodeH& x = N[i];
+        if (x.leaf || x.level > swlevel || x.ni < (int)opts.hss_d * 1024 || !x.mine) continue;
+        if (x.nb > 0 && !x.compressed) continue;  // |bnd| < swsize: stays dense like in the reference
+        x.hssd = true;
+        x.ilv = hss_interleave_perm(h->fidx_host.data() + x.off_fidx, x.ni, x.ni1, n, colptr, rowval, where);
+      }
+    }
     for (auto& L : h->levels) {  // dense fronts first: they are eliminated as one batch, compressed fronts one by one
       std::vector<int> ord;
-      for (int pass = 0; pass < 2; ++pass)
+      for (int pass = 0; pass < 3; ++pass)
         for (int id : L.mine)
-          if ((int)N[id].compressed == pass) ord.push_back(id);
+          if ((N[id].hssd ? 2 : (int)N[id].compressed) == pass) ord.push_back(id);
       L.mine = ord;
+      L.nplain = 0;
+      for (int id : L.mine)
+        if (N[id].compressed && !N[id].hssd) L.nplain++;
       L.h_ni.clear();
       L.h_nb.clear();
       L.ndense = 0;
@@ -487,7 +513,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         x.batch_pos = (int)k;
         L.h_ni.push_back(x.ni);
         L.h_nb.push_back(x.nb);
-        if (!x.compressed) {
+        if (!x.compressed && !x.hssd) {
           L.ndense = (int)k + 1;
           L.dmaxni = std::max(L.dmaxni, x.ni);
           L.dmaxnb = std::max(L.dmaxnb, x.nb);
@@ -700,6 +726,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           q.ni = x.ni; q.nb = x.nb; q.m = x.m; q.ldl = x.ldl; q.ldu = x.ldu;
           q.compressed = x.compressed ? 1 : 0;
           q.mrows = x.compressed ? x.ni : x.m;
+          if (x.hssd) q.ni = q.nb = q.m = q.mrows = 0;  // the dense sweeps skip it: solve_hss_fwd / solve_hss_bwd (hs_hssfront.h)
           q.woff = x.woff;
           q.poff = poff;
           poff += (long long)((x.nb + 511) / 512) * x.ni;
@@ -769,6 +796,7 @@ template <class T>
 static void numeric_begin(hs_handle* h, const void* nzval, int on_device) {
   if (!nzval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: nzval == NULL");
   hipStream_t s = h->stream;
+  free_hss_nodes<T>(h);
   free_lowrank_nodes<T>(h);
   HS_HIP(hipMemcpyAsync(h->d_nz, nzval, h->nnz * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   HS_HIP(hipMemsetAsync(h->d_own, 0xff, h->n * sizeof(int), s));
@@ -840,7 +868,8 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
       h->optimistic = false;
       if (h->opts.verbose) fprintf(stderr, "[hs] level %d: a pivot outside the diagonal block was needed; redoing the level with tournament pivoting\n", lv);
     }
-    if (nb_ > L.ndense) factor_compressed_level<T>(h, L.mine.data() + L.ndense, nb_ - L.ndense, dn + L.ndense, (const SolveNode<T>*)h->d_solve + L.desc_off + L.ndense);  // hs_compress.h
+    if (L.nplain > 0) factor_compressed_level<T>(h, L.mine.data() + L.ndense, L.nplain, dn + L.ndense, (const SolveNode<T>*)h->d_solve + L.desc_off + L.ndense);  // hs_compress.h
+    if (nb_ > L.ndense + L.nplain) factor_hss_fronts<T>(h, L.mine.data() + L.ndense + L.nplain, nb_ - L.ndense - L.nplain, dn + L.ndense + L.nplain);  // hs_hssfront.h
     static const bool lvl_env = getenv("HS_VERBOSE_LEVELS") != nullptr;
     if (h->opts.profile || lvl_env) {  // per-level wall time (HS_VERBOSE_LEVELS=1 prints it at hs_numeric_end)
       hipEvent_t e = nullptr;
@@ -930,6 +959,7 @@ static void solve_fwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
       for (int blk = 0; blk < nblk; ++blk) launch_fwd_step<T>(dn, nb_, blk, L.maxm, w1, w2, db, s);
     }
     solve_lr_fwd<T>(h, lv, db, s);
+    solve_hss_fwd<T>(h, lv, db, s);
   }
 }
 template <class T>
@@ -957,6 +987,7 @@ static void solve_bwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
       for (int blk = nblk - 1; blk >= 0; --blk) launch_bwd_step<T>(dn, nb_, blk, w1, w2, s);
     }
     launch_bwd_scatter<T>(dn, nb_, L.maxni, db, w2, s);
+    solve_hss_bwd<T>(h, lv, db, s);
   }
 }
 
@@ -1257,6 +1288,7 @@ extern "C" int hs_node_info(const hs_handle* F, int64_t node, int64_t* ni, int64
 template <class T>
 static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) {
   if (!x.mine) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: node is owned by rank %d", x.owner);
+  if (x.hssd) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "the interior block of this node is an HSS matrix (hs_options.hss_d): it has no dense D, L, R blocks");
   if (x.compressed && (which == HS_BLK_LBI || which == HS_BLK_UIB)) {  // dense reconstruction C*Z of the low-rank transform
     const void* lr = which == HS_BLK_LBI ? x.lrL : x.lrR;
     if (!lr) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: node has no compressed Gauss transforms yet");

@@ -276,7 +276,7 @@ static void solve_lr_fwd(hs_handle* h, int lv, T* db, hipStream_t s) {
   T* w2 = (T*)h->d_w2;  // y = L11^-1 P rhs[int]
   for (int id : L.mine) {
     const NodeH& x = h->nodes[id];
-    if (!x.compressed || !x.lrL) continue;
+    if (!x.compressed || !x.lrL || x.hssd) continue;
     const LowRank<T>& lr = *(const LowRank<T>*)x.lrL;
     if (lr.r == 0) continue;
     ensure_lr_workspace<T>(h, lr.r, lr.cols);
@@ -292,7 +292,7 @@ static void solve_lr_bwd(hs_handle* h, int lv, T* db, hipStream_t s) {
   T* w1 = (T*)h->d_w1;
   for (int id : L.mine) {
     const NodeH& x = h->nodes[id];
-    if (!x.compressed || !x.lrR) continue;
+    if (!x.compressed || !x.lrR || x.hssd) continue;
     const LowRank<T>& lr = *(const LowRank<T>*)x.lrR;
     if (lr.r == 0) continue;
     ensure_lr_workspace<T>(h, lr.r, lr.cols);

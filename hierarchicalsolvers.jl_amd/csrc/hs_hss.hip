@@ -206,12 +206,15 @@ struct HssT {
   std::vector<std::vector<int>> lev;
   Pool keep;  // generators and factors
   hipStream_t s = nullptr;
+  bool own_stream = false;
+  int* perm = nullptr;  // device, n entries (0-based) or null: H ~= A[perm, perm]
+  Pool permpool;
   bool factored = false;
   NodeDesc<T> rootfd;  // LU of the last block
   int root_m = 0;
   double t_compress = 0.0, t_factor = 0.0;
   ~HssT() {
-    if (s) (void)hipStreamDestroy(s);
+    if (s && own_stream) (void)hipStreamDestroy(s);
   }
 };
 
@@ -338,24 +341,36 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
     x.m = n;
     x.ldd = ev(n);
     x.D = H.keep.template get<T>((size_t)x.ldd * n);
-    subs.push_back(SubJob<T>{A, lda, nullptr, nullptr, 0, 0, n, n, x.D, x.ldd, 0});
+    subs.push_back(SubJob<T>{A, lda, H.perm, H.perm, 0, 0, n, n, x.D, x.ldd, 0});
     run_subs(tmp, subs, s);
     HSS_HIP(hipStreamSynchronize(s));
     return true;
   }
-  // test matrices OP = [Omega | Psi] (n x 2k) and samples Y = [A*Omega | A^T*Psi]
+  // test matrices OP = [Omega | Psi] (n x 2k) and samples Y = [B*Omega | B^T*Psi] of B = A[perm, perm]:
+  // B*Omega = (A * Omega')[perm] with Omega'[perm[i]] = Omega[i]; B^T*Psi likewise from Psi'^T * A
   T* OP = tmp.get<T>((size_t)ldn * k2);
   T* Y = tmp.get<T>((size_t)ldn * k2);
   T* PsT = tmp.get<T>((size_t)ldk * n);
   T* W = tmp.get<T>((size_t)ldk * n);
-  fill_randn<T>(OP, n, ldn, k, (uint64_t)H.opt.seed * 0x9E3779B97F4A7C15ull + 17 * (uint64_t)k, s);
-  fill_randn<T>(PsT, k, ldk, n, (uint64_t)H.opt.seed * 0xD1B54A32D192ED03ull + 29 * (uint64_t)k + 1, s);
-  gemms.push_back(GemmProb<T>{A, OP, Y, n, k, n, lda, ldn, ldn});
+  fill_randn<T>(OP, n, ldn, k2, (uint64_t)H.opt.seed * 0x9E3779B97F4A7C15ull + 17 * (uint64_t)k, s);
+  T *OPs = OP, *Ys = Y;
+  if (H.perm) {
+    OPs = tmp.get<T>((size_t)ldn * k2);
+    Ys = tmp.get<T>((size_t)ldn * k2);
+    rows.push_back(RowJob<T>{OP, ldn, OPs, ldn, H.perm, n, k2, ROW_SCATTER});
+    run_rows(tmp, rows, s);
+  }
+  subs.push_back(SubJob<T>{OPs + (size_t)ldn * k, ldn, nullptr, nullptr, 0, 0, n, k, PsT, ldk, 1});
+  run_subs(tmp, subs, s);
+  gemms.push_back(GemmProb<T>{A, OPs, Ys, n, k, n, lda, ldn, ldn});
   gemms.push_back(GemmProb<T>{PsT, A, W, k, n, n, ldk, lda, ldk});
   run_gemms(tmp, gemms, 0, s);
-  subs.push_back(SubJob<T>{PsT, ldk, nullptr, nullptr, 0, 0, k, n, OP + (size_t)ldn * k, ldn, 1});
-  subs.push_back(SubJob<T>{W, ldk, nullptr, nullptr, 0, 0, k, n, Y + (size_t)ldn * k, ldn, 1});
+  subs.push_back(SubJob<T>{W, ldk, nullptr, nullptr, 0, 0, k, n, Ys + (size_t)ldn * k, ldn, 1});
   run_subs(tmp, subs, s);
+  if (H.perm) {
+    rows.push_back(RowJob<T>{Ys, ldn, Y, ldn, H.perm, n, k2, ROW_GATHER});
+    run_rows(tmp, rows, s);
+  }
 
   const int N = (int)nd.size();
   // local sample / test blocks of every node (leaf: rows lo:hi of Y / OP), global index of every local position
@@ -381,8 +396,10 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
         x.ldd = ev(m);
         x.D = H.keep.template get<T>((size_t)x.ldd * m);
         DT[i] = tmp.get<T>((size_t)x.ldd * m);
-        subs.push_back(SubJob<T>{A, lda, nullptr, nullptr, x.lo, x.lo, m, m, x.D, x.ldd, 0});
-        subs.push_back(SubJob<T>{A, lda, nullptr, nullptr, x.lo, x.lo, m, m, DT[i], x.ldd, 1});
+        const int* pl = H.perm ? H.perm + x.lo : nullptr;  // rows / columns of A behind the leaf's positions
+        const int o0 = H.perm ? 0 : x.lo;
+        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, x.D, x.ldd, 0});
+        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, DT[i], x.ldd, 1});
         gemms.push_back(GemmProb<T>{x.D, Ol[i], Yl[i], m, k, m, x.ldd, ldl[i], ldl[i]});
         gemms.push_back(GemmProb<T>{DT[i], Ol[i] + (size_t)ldl[i] * k, Yl[i] + (size_t)ldl[i] * k, m, k, m, x.ldd, ldl[i], ldl[i]});
       } else {
@@ -461,7 +478,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
         x.Tm = H.keep.template get<T>((size_t)x.ldt * r);
         x.Tt = H.keep.template get<T>((size_t)x.ldtt * std::max(nR, 1));
         if (nR > 0) ts.push_back(TsJob<T>{lr[a].Lp, lr[a].ldp, m, r, x.Tm, x.ldt, x.Tt, x.ldtt});
-        ij.push_back(IdxJob{x.p, Jidx[i], x.lo, r, x.sk});
+        ij.push_back(IdxJob{x.p, (x.left < 0 && H.perm) ? H.perm + x.lo : Jidx[i], x.lo, r, x.sk});
         maxR = std::max(maxR, nR);
         maxr = std::max(maxr, r);
       }
@@ -534,7 +551,27 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
 // Y = H * X
 // ------------------------------------------------------------------------------------------------
 template <class T>
+void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q);
+// Y = H * X in the caller's index order: the tree works on the permuted vectors
+template <class T>
 void hss_mul(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q) {
+  if (!H.perm) {
+    hss_mul_p(H, X, ldx, Y, ldy, q);
+    return;
+  }
+  Pool tmp;
+  const int ld = ev(H.n);
+  T* Xp = tmp.get<T>((size_t)ld * q);
+  T* Yp = tmp.get<T>((size_t)ld * q);
+  std::vector<RowJob<T>> rows{RowJob<T>{X, ldx, Xp, ld, H.perm, H.n, q, ROW_GATHER}};
+  run_rows(tmp, rows, H.s);
+  hss_mul_p(H, Xp, ld, Yp, ld, q);
+  rows.push_back(RowJob<T>{Yp, ld, Y, ldy, H.perm, H.n, q, ROW_SCATTER});
+  run_rows(tmp, rows, H.s);
+  HSS_HIP(hipStreamSynchronize(H.s));
+}
+template <class T>
+void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q) {
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
@@ -777,7 +814,25 @@ NodeDesc<T> rhs_desc(const NodeDesc<T>& f, T* B, int ldb, int q) {
 }
 
 template <class T>
+void hss_ldiv_p(HssT<T>& H, T* B, int ldb, int q);
+template <class T>
 void hss_ldiv(HssT<T>& H, T* B, int ldb, int q) {
+  if (!H.perm) {
+    hss_ldiv_p(H, B, ldb, q);
+    return;
+  }
+  Pool tmp;
+  const int ld = ev(H.n);
+  T* Bp = tmp.get<T>((size_t)ld * q);
+  std::vector<RowJob<T>> rows{RowJob<T>{B, ldb, Bp, ld, H.perm, H.n, q, ROW_GATHER}};
+  run_rows(tmp, rows, H.s);
+  hss_ldiv_p(H, Bp, ld, q);
+  rows.push_back(RowJob<T>{Bp, ld, B, ldb, H.perm, H.n, q, ROW_SCATTER});
+  run_rows(tmp, rows, H.s);
+  HSS_HIP(hipStreamSynchronize(H.s));
+}
+template <class T>
+void hss_ldiv_p(HssT<T>& H, T* B, int ldb, int q) {
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
@@ -853,7 +908,7 @@ void hss_ldiv(HssT<T>& H, T* B, int ldb, int q) {
 }
 
 template <class T>
-HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_hss_options* o) {
+HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_hss_options* o, const int64_t* perm = nullptr, void* stream = nullptr) {
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
     hs_set_error(HS_ERR_DEVICE, 0, "no HIP device available (the HSS module has no CPU fallback)");
@@ -875,7 +930,26 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
   std::unique_ptr<HssT<T>> H(new HssT<T>());
   H->n = (int)n;
   H->opt = opt;
-  HSS_HIP(hipStreamCreate(&H->s));
+  if (stream) {
+    H->s = (hipStream_t)stream;
+  } else {
+    HSS_HIP(hipStreamCreate(&H->s));
+    H->own_stream = true;
+  }
+  if (perm) {  // must be a permutation of 0..n-1
+    std::vector<int> hp((size_t)n);
+    std::vector<char> seen((size_t)n, 0);
+    for (int64_t i = 0; i < n; ++i) {
+      if (perm[i] < 0 || perm[i] >= n || seen[(size_t)perm[i]]) {
+        hs_set_error(HS_ERR_ARGUMENT, i, "ArgumentError: perm is not a permutation of 0..n-1 (entry %lld)", (long long)i);
+        throw (int)HS_ERR_ARGUMENT;
+      }
+      seen[(size_t)perm[i]] = 1;
+      hp[(size_t)i] = (int)perm[i];
+    }
+    H->perm = H->permpool.template get<int>((size_t)n);
+    HSS_HIP(hipMemcpy(H->perm, hp.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  }
   Pool in;
   const T* dA = A;
   int ld = (int)lda;
@@ -939,6 +1013,33 @@ extern "C" int hs_hss_compress_z(int64_t n, const double* A, int64_t lda, int wh
 #define HSS_DISPATCH(H, expr_d, expr_z) ((H)->is_complex ? (expr_z) : (expr_d))
 #define HD(H) ((HssT<double>*)(H)->impl)
 #define HZ(H) ((HssT<cplx>*)(H)->impl)
+
+extern "C" int hs_hss_compress_ex_d(int64_t n, const double* A, int64_t lda, int where, const int64_t* perm, const hs_hss_options* o, void* stream,
+                                    hs_hss** out) {
+  if (!out) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  HSS_GUARD(*out = new hs_hss{0, compress_impl<double>(n, A, lda, where, o, perm, stream)});
+}
+extern "C" int hs_hss_compress_ex_z(int64_t n, const double* A, int64_t lda, int where, const int64_t* perm, const hs_hss_options* o, void* stream,
+                                    hs_hss** out) {
+  if (!out) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  HSS_GUARD(*out = new hs_hss{1, compress_impl<cplx>(n, (const cplx*)A, lda, where, o, perm, stream)});
+}
+
+extern "C" int hs_hss_set_stream(hs_hss* H, void* stream) {
+  if (!H) return HS_ERR_ARGUMENT;  // stream == NULL: the default stream
+  if (H->is_complex) {
+    if (HZ(H)->own_stream && HZ(H)->s) (void)hipStreamDestroy(HZ(H)->s);
+    HZ(H)->s = (hipStream_t)stream;
+    HZ(H)->own_stream = false;
+  } else {
+    if (HD(H)->own_stream && HD(H)->s) (void)hipStreamDestroy(HD(H)->s);
+    HD(H)->s = (hipStream_t)stream;
+    HD(H)->own_stream = false;
+  }
+  return HS_OK;
+}
 
 extern "C" int64_t hs_hss_size(const hs_hss* H) { return H ? HSS_DISPATCH(H, HD(H)->n, HZ(H)->n) : 0; }
 extern "C" int64_t hs_hss_samples(const hs_hss* H) { return H ? HSS_DISPATCH(H, HD(H)->k, HZ(H)->k) : 0; }

@@ -123,8 +123,9 @@ class HssMatrix:
         return self.matmul(np.eye(self.shape[0], dtype=self.dtype))
 
 
-def compress(A, cl=None, *, leafsize=64, atol=1e-6, rtol=1e-6, kest=64, seed=123, pad=8, level_scale=0.5):
-    """``compress(A, cl, cl; atol, rtol)``: HSS form of the dense matrix ``A`` on the GPU."""
+def compress(A, cl=None, *, leafsize=64, atol=1e-6, rtol=1e-6, kest=64, seed=123, pad=8, level_scale=0.5, perm=None):
+    """``compress(A, cl, cl; atol, rtol)``: HSS form of the dense matrix ``A`` on the GPU (``perm``: 0-based
+    permutation, the tree is built over ``A[perm][:, perm]``; products and solves keep the caller's order)."""
     A = np.asarray(A)
     n = A.shape[0]
     if A.ndim != 2 or A.shape[1] != n:
@@ -137,8 +138,14 @@ def compress(A, cl=None, *, leafsize=64, atol=1e-6, rtol=1e-6, kest=64, seed=123
     o = _lib.hs_hss_options(leaf, first, atol, rtol, kest, pad, seed, level_scale)
     h = C.c_void_p()
     L = _lib.lib()
-    f = L.hs_hss_compress_z if is_c else L.hs_hss_compress_d
-    _lib.check(f(n, Af.ctypes.data_as(C.c_void_p), n, 0, C.byref(o), C.byref(h)))
+    f = L.hs_hss_compress_ex_z if is_c else L.hs_hss_compress_ex_d
+    pp = None
+    if perm is not None:
+        perm = np.ascontiguousarray(perm, dtype=np.int64)
+        if perm.shape != (n,):
+            raise _lib.DimensionMismatch(f"perm has {perm.shape} entries, the matrix has {n} rows")
+        pp = perm.ctypes.data_as(_lib.p_i64)
+    _lib.check(f(n, Af.ctypes.data_as(C.c_void_p), n, 0, pp, C.byref(o), None, C.byref(h)))
     return HssMatrix(h, is_c)
 
 

@@ -31,7 +31,7 @@ class SolverOptions:
     ``5, 1, 1e-6, 1e-6, 0.5, 32, -1, 10, false`` (HierarchicalSolvers.jl:43-54)."""
 
     _fields = ("swlevel", "swsize", "atol", "rtol", "c_tol", "leafsize", "kest", "stepsize", "verbose")
-    _ext = ("keep_schur", "seed", "profile", "split_size")
+    _ext = ("keep_schur", "seed", "profile", "split_size", "hss_min")
 
     def __init__(self, **kw):
         self.swlevel, self.swsize = 5, 1
@@ -42,6 +42,7 @@ class SolverOptions:
         self.profile = False
         self.seed = 123
         self.split_size = 0  # columns per slice of a compressed front's interior block (multiple of 256, 0 = off)
+        self.hss_min = 0  # > 0 (multiple of 1024): compressed-level fronts with at least this many interior DOFs keep D as HSS
         self._set(kw)
 
     def _set(self, kw):
@@ -71,6 +72,10 @@ class SolverOptions:
         if ss < 0 or ss % 256 or ss // 256 > 255:
             raise ValueError("split_size must be a multiple of 256 in 0:65280")
         o.split = ss // 256
+        hm = int(self.hss_min)
+        if hm < 0 or hm % 1024 or hm // 1024 > 255:
+            raise ValueError("hss_min must be a multiple of 1024 in 0:261120")
+        o.hss_d = hm // 1024
         return o
 
 

@@ -49,6 +49,17 @@ void hs_hss_options_default(hs_hss_options* o); /* 64, 0, 1e-6, 1e-6, 64, 8, 123
 int hs_hss_compress_d(int64_t n, const double* A, int64_t lda, int where, const hs_hss_options* o, hs_hss** out);
 int hs_hss_compress_z(int64_t n, const double* A, int64_t lda, int where, const hs_hss_options* o, hs_hss** out);
 
+/* The same for H ~= A[perm, perm] (perm: n 0-based indices on the HOST, NULL = identity; products and solves keep the
+ * caller's index order) on HIP stream `stream` (hipStream_t; NULL: a private stream).  The elimination uses it for the
+ * interior block of a front, whose two separator layers are listed one after the other: the
+ * permutation interleaves them so that an index range of the cluster tree is a compact patch of the separator. */
+int hs_hss_compress_ex_d(int64_t n, const double* A, int64_t lda, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
+int hs_hss_compress_ex_z(int64_t n, const double* A, int64_t lda, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
+
+/* later products / eliminations / solves run on `stream` (hipStream_t; NULL = the default stream); every call still returns only after its
+ * work on that stream has completed */
+int hs_hss_set_stream(hs_hss* H, void* stream);
+
 int64_t hs_hss_rank(const hs_hss* H);      /* hssrank: largest rank of an off-diagonal block */
 int64_t hs_hss_size(const hs_hss* H);      /* n */
 int64_t hs_hss_samples(const hs_hss* H);   /* samples per side the adaptive compression ended with */

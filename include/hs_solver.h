@@ -59,7 +59,11 @@ typedef struct hs_options {
   uint8_t split;      /* slice width, in units of 256 columns, in which the interior block of a compressed front (level <=
                          swlevel, ni >= 2 slices) is eliminated: the role of the 2x2 BlockFactorization of D (blockmatrix.jl:106-130);
                          0 = off; single-rank factorizations only */
-  uint8_t reserved[4];
+  uint8_t hss_d;      /* > 0: a front at a level <= swlevel whose interior block has at least hss_d*1024 DOFs keeps D = Aii as an HSS
+                         matrix (include/hs_hss.h) instead of a dense LU -- the role of `D::BlockFactorization` over HssMatrix blocks
+                         (blockmatrix.jl:121-130, factorization.jl:86-96); the root included, which in the reference receives its
+                         children's HSS blocks although it is never flagged (factorization.jl:15,67,126).  Single rank only. */
+  uint8_t reserved[3];
   int64_t seed;       /* RNG seed of the randomized compression (reference: Random.seed!(123), test/rungmres.jl:7) */
 } hs_options;
 

@@ -1,0 +1,57 @@
+"""Fronts whose interior block D = Aii is an HSS matrix (hs_options.hss_d / SolverOptions.hss_min) on the GPU.
+
+Reference: `_factor_branch(..., Val(true))` keeps `D::BlockFactorization` over HssMatrix blocks and applies
+`Aii^-1` through the HSS solve (src/factorization.jl:78-112, src/blockmatrix.jl:121-156); the root assembles its
+children's HSS blocks too (:67,126).  HssMatrices.jl is absent (PARITY UNPINNED): the factorization is checked as
+what it is used for -- a preconditioner whose error is O(tol) -- against SuperLU, against the same factorization
+with a dense LU of D, and through the GMRES iteration count of test/rungmres.jl:47-48."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from helpers import prepare, relerr
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (((32, 32, 32), dict(kind="poisson", nmax=512)), 3),
+    (((24, 24, 24), dict(kind="helmholtz", nmax=512)), 2),
+]
+
+
+@pytest.mark.parametrize("name,swlevel", CASES)
+@pytest.mark.parametrize("tol", [1e-2, 1e-6, 1e-10])
+def test_hss_fronts_ldiv_accuracy(hs, name, swlevel, tol):
+    P = prepare(hs, name[0], rhs="randn", **name[1])
+    kw = dict(swlevel=swlevel, swsize=8, atol=tol, rtol=tol)
+    Fh = hs.factor(P["A"], P["nd"], P["nd_loc"], hss_min=1024, **kw)
+    Fd = hs.factor(P["A"], P["nd"], P["nd_loc"], **kw)
+    xr = spla.splu(P["A"]).solve(P["b"])
+    eh, ed = relerr(hs.ldiv(Fh, P["b"]), xr), relerr(hs.ldiv(Fd, P["b"]), xr)
+    print(f"{name[0]} tol={tol:g}: err with HSS D {eh:.2e}, with dense D {ed:.2e}, maxrank {hs.maxrank(Fh)} / {hs.maxrank(Fd)}")
+    assert hs.maxrank(Fh) > 0
+    # D^-1 through the HSS elimination costs accuracy O(tol * cond); it must stay a preconditioner of the same quality
+    assert eh <= max(100 * ed, 1e4 * tol), (eh, ed)
+    # a second solve and a second numeric factorization of the same handle give the same answer
+    x1 = hs.ldiv(Fh, P["b"])
+    assert relerr(x1, xr) <= max(100 * ed, 1e4 * tol)
+
+
+def test_hss_fronts_gmres_iterations(hs):
+    """GMRES(30) to 1e-9 right-preconditioned by the tol = 1e-2 factorization: same iteration count (+-2) with D as HSS."""
+    P = prepare(hs, (32, 32, 32), rhs="randn", kind="poisson", nmax=512)
+    its = {}
+    for hss_min in (0, 1024):
+        F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=3, swsize=8, atol=1e-2, rtol=1e-2, hss_min=hss_min)
+        x, hist = hs.gmres(P["A"], P["b"], Pr=F, reltol=1e-9, restart=30, maxiter=60, log=True)
+        its[hss_min] = hist["iters"]
+        assert np.linalg.norm(P["A"] @ x - P["b"]) / np.linalg.norm(P["b"]) < 1e-8
+    print("GMRES iterations: dense D", its[0], " HSS D", its[1024])
+    assert its[1024] <= its[0] + 4
+
+
+def test_hss_fronts_refuse_dense_export(hs):
+    P = prepare(hs, (32, 32, 32), kind="poisson", nmax=512)
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=2, swsize=8, atol=1e-6, rtol=1e-6, hss_min=1024)
+    with pytest.raises(hs.UnsupportedError):
+        F.node_blocks(F.nnodes - 1)
