@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--swsize", type=int, default=8)
     ap.add_argument("--tol", type=float, default=1e-6, help="atol = rtol of the compressed fronts")
     ap.add_argument("--split", type=int, default=0, help="slice width (multiple of 256) in which compressed fronts eliminate their interior block; 0 = off")
+    ap.add_argument("--hss-min", type=int, default=0, help="fronts of the compressed levels with at least this many interior DOFs (multiple of 1024) keep D = Aii as an HSS matrix; 0 = dense LU of D")
     args = ap.parse_args()
 
     import numpy as np
@@ -112,7 +113,7 @@ def main():
     t_host = time.perf_counter() - t0
     is_c = np.iscomplexobj(Ap.data)
 
-    fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol, split_size=args.split) if args.swlevel != 0 else dict(swlevel=0)
+    fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol, split_size=args.split, hss_min=args.hss_min) if args.swlevel != 0 else dict(swlevel=0)
     t0 = time.perf_counter()
     S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, **fopts)
     torch.cuda.synchronize(dev)
@@ -221,7 +222,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "n": int(Ap.shape[0]), "nnz": int(Ap.nnz), "tree_nodes": int(st["nnodes"]),
                        "tree_depth": int(st["nlevels"]), "max_front": [int(st["max_ni"]), int(st["max_nb"])], "nrhs": 1,
-                       "compression": "none (swlevel=0)" if args.swlevel == 0 else f"low-rank off-diagonal blocks, swlevel={args.swlevel} swsize={args.swsize} atol=rtol={args.tol:g} split={args.split}",
+                       "compression": "none (swlevel=0)" if args.swlevel == 0 else f"low-rank off-diagonal blocks, swlevel={args.swlevel} swsize={args.swsize} atol=rtol={args.tol:g} split={args.split} hss_min={args.hss_min}",
                        "partition": f"subtree-per-rank x{world}"},
             "factor_s": st["t_total"],
             "residual": res,

@@ -107,28 +107,27 @@ __global__ __launch_bounds__(64) void sub_gather_kernel(const SubJob<T>* __restr
   }
 }
 
-// interpolation matrix of a row ID from the packed L\U of its pivoted samples: T = L21 * L11^-1 ((m-r) x r), and T^T.
-// One thread per row of L21: t * L11 = l by back substitution over the columns (L11 unit lower triangular).
+// interpolation matrix of a row ID from the packed L\U of its pivoted samples: T = L21 * L11^-1 ((m-r) x r), L11 unit lower
+// triangular.  Blocked by 32 columns from the right (compress_fixed): the update with the finished columns is an MFMA GEMM,
+// this kernel finishes one block -- one thread per row, back substitution inside the block (a one-kernel version with the
+// whole substitution per thread was 25 % of all device time of a factorization with HSS interior blocks).
 template <class T>
 struct TsJob {
   const T* Lp;
   int ldp, m, r;
   T* Tm;
   int ldt;
-  T* Tt;
-  int ldtt;
+  int j0, j1;  // columns [j0, j1) of T
 };
 template <class T>
-__global__ __launch_bounds__(64) void tsolve_kernel(const TsJob<T>* __restrict__ jobs) {
+__global__ __launch_bounds__(64) void tsolve_block_kernel(const TsJob<T>* __restrict__ jobs) {
   const TsJob<T> j = jobs[blockIdx.y];
   const int row = blockIdx.x * 64 + threadIdx.x;
   if (row >= j.m - j.r) return;
-  const T* l = j.Lp + j.r + row;
-  for (int c = j.r - 1; c >= 0; --c) {
-    T acc = l[(size_t)c * j.ldp];
-    for (int q = c + 1; q < j.r; ++q) acc = Scal<T>::fnma(j.Tm[(size_t)row + (size_t)q * j.ldt], j.Lp[(size_t)q + (size_t)c * j.ldp], acc);
+  for (int c = j.j1 - 1; c >= j.j0; --c) {
+    T acc = j.Tm[(size_t)row + (size_t)c * j.ldt];
+    for (int q = c + 1; q < j.j1; ++q) acc = Scal<T>::fnma(j.Tm[(size_t)row + (size_t)q * j.ldt], j.Lp[(size_t)q + (size_t)c * j.ldp], acc);
     j.Tm[(size_t)row + (size_t)c * j.ldt] = acc;
-    j.Tt[(size_t)c + (size_t)row * j.ldtt] = acc;
   }
 }
 
@@ -462,7 +461,6 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
       free_lr();
       return false;
     }
-    std::vector<TsJob<T>> ts;
     std::vector<IdxJob> ij;
     int maxR = 0, maxr = 0;
     try {
@@ -477,14 +475,50 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
         x.ldtt = ev(r);
         x.Tm = H.keep.template get<T>((size_t)x.ldt * r);
         x.Tt = H.keep.template get<T>((size_t)x.ldtt * std::max(nR, 1));
-        if (nR > 0) ts.push_back(TsJob<T>{lr[a].Lp, lr[a].ldp, m, r, x.Tm, x.ldt, x.Tt, x.ldtt});
+        subs.push_back(SubJob<T>{lr[a].Lp, lr[a].ldp, nullptr, nullptr, r, 0, nR, r, x.Tm, x.ldt, 0});  // T <- L21
         ij.push_back(IdxJob{x.p, (x.left < 0 && H.perm) ? H.perm + x.lo : Jidx[i], x.lo, r, x.sk});
         maxR = std::max(maxR, nR);
         maxr = std::max(maxr, r);
       }
-      if (!ts.empty()) {
+      run_subs(tmp, subs, s);
+      if (maxR > 0) {
+        // T = L21 * L11^-1, 32 columns at a time from the right; the descriptors of every step are uploaded once
+        std::vector<GemmProb<T>> gp;
+        std::vector<TsJob<T>> ts;
+        struct Step {
+          size_t g0, gn, t0, tn;
+          int mN;
+        };
+        std::vector<Step> steps;
+        for (int j0 = (maxr - 1) / 32 * 32; j0 >= 0; j0 -= 32) {
+          Step st{gp.size(), 0, ts.size(), 0, 0};
+          for (int a = 0; a < nj; ++a) {
+            const HNode<T>& x = nd[L[a]];
+            const int r = x.r, nR = x.m - r;
+            if (nR <= 0 || r <= j0) continue;
+            const int j1 = std::min(j0 + 32, r);
+            if (r > j1) {
+              gp.push_back(GemmProb<T>{x.Tm + (size_t)j1 * x.ldt, lr[a].Lp + j1 + (size_t)j0 * lr[a].ldp, x.Tm + (size_t)j0 * x.ldt, nR, j1 - j0, r - j1, x.ldt,
+                                       lr[a].ldp, x.ldt});
+              st.mN = std::max(st.mN, j1 - j0);
+            }
+            ts.push_back(TsJob<T>{lr[a].Lp, lr[a].ldp, x.m, r, x.Tm, x.ldt, j0, j1});
+          }
+          st.gn = gp.size() - st.g0;
+          st.tn = ts.size() - st.t0;
+          steps.push_back(st);
+        }
+        GemmProb<T>* dgp = upload(tmp, gp);
         TsJob<T>* dts = upload(tmp, ts);
-        hipLaunchKernelGGL(tsolve_kernel<T>, dim3((maxR + 63) / 64, (unsigned)ts.size()), dim3(64), 0, s, (const TsJob<T>*)dts);
+        for (const Step& st : steps) {
+          if (st.gn > 0) launch_gemm_probs<T>(dgp + st.g0, (int)st.gn, maxR, st.mN, 1, s);
+          if (st.tn > 0) hipLaunchKernelGGL(tsolve_block_kernel<T>, dim3((maxR + 63) / 64, (unsigned)st.tn), dim3(64), 0, s, (const TsJob<T>*)(dts + st.t0));
+        }
+        for (int a = 0; a < nj; ++a) {
+          const HNode<T>& x = nd[L[a]];
+          subs.push_back(SubJob<T>{x.Tm, x.ldt, nullptr, nullptr, 0, 0, x.m - x.r, x.r, x.Tt, x.ldtt, 1});  // T^T
+        }
+        run_subs(tmp, subs, s);
       }
       IdxJob* dij = upload(tmp, ij);
       hipLaunchKernelGGL(idx_compose_kernel, dim3((maxr + 63) / 64, (unsigned)ij.size()), dim3(64), 0, s, (const IdxJob*)dij);
