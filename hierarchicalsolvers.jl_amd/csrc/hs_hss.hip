@@ -424,22 +424,20 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
     }
     run_subs(tmp, subs, s);
     run_gemms(tmp, gemms, 1, s);
-    // ---- b. row IDs of the sample blocks [Sr | Sc] (the ID destroys its input: work on copies) ----------------------------
+    // ---- b. row IDs of the sample blocks [Sr | Sc] (read in place: without Z the ID leaves its input alone) -----------------
     std::vector<LowRank<T>> lr(nj);
     std::vector<LowRankJob<T>> jobs(nj);
     for (int a = 0; a < nj; ++a) {
       const int i = L[a];
-      const int m = nd[i].m, ldx = ev(m);
-      T* X = tmp.get<T>((size_t)ldx * k2);
-      rows.push_back(RowJob<T>{Yl[i], ldl[i], X, ldx, nullptr, m, k2, ROW_GATHER});
-      jobs[a] = LowRankJob<T>{X, ldx, m, k2, 1 << 30, (uint64_t)H.opt.seed + 7919ull * (uint64_t)i, &lr[a], 0};
+      // sketch width k: the adaptive rule below keeps every rank under k - pad (a block that gets closer is redone at 2k by the ID itself)
+      jobs[a] = LowRankJob<T>{Yl[i], ldl[i], nd[i].m, k2, k, (uint64_t)H.opt.seed + 7919ull * (uint64_t)i, &lr[a], 0};
     }
     run_rows(tmp, rows, s);
     // deeper levels are truncated more tightly: the error they hand up must stay below the threshold of the levels above
     // (with one tolerance everywhere the sample blocks of the upper levels sit on a noise plateau AT the threshold and the
     // pivoted-LU rank detection reads it as rank: measured 45 instead of 18 at 1e-8 on the test kernel)
     const double lsc = std::pow(H.opt.level_scale, lv - 1);
-    const int st = lowrank_compress_batch<T>(jobs.data(), nj, H.opt.atol * lsc, H.opt.rtol * lsc, s);
+    const int st = lowrank_compress_batch<T>(jobs.data(), nj, H.opt.atol * lsc, H.opt.rtol * lsc, s, false);
     auto free_lr = [&]() {
       for (auto& q : lr) lowrank_free(q);
     };

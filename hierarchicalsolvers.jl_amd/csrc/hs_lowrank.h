@@ -28,7 +28,9 @@ struct LowRankJob {
   int k;           // work: current sketch width
 };
 template <class T>
-int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s);
+// need_z = false: only the pivoted LU of the sketch, the row permutation and the rank are wanted (the HSS module takes its
+// interpolation matrices from them): Z is not formed and X is left as it was
+int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z = true);
 // hs_lrdense.hip
 template <class T>
 void lowrank_expand(LowRank<T>& lr, hipStream_t s);  // fills Cd from the trapezoid form

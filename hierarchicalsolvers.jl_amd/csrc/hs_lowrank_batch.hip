@@ -79,7 +79,7 @@ struct Guard {  // frees what it was given, whatever the exit path
   } while (0)
 
 template <class T>
-int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s) {
+int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z) {
   std::vector<int> todo;
   for (int i = 0; i < njobs; ++i) {
     LowRankJob<T>& J = jobs[i];
@@ -234,21 +234,23 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
         hs_set_error(-6, 0, "upload of the compression descriptors failed: %s", hipGetErrorString(e));
         return -6;
       }
-      sch.laswp(HS_MAT_UR, 0, HS_BIG, 0, P2);
-      sch.trsm_rec(HS_MAT_UR, 0, P2, 0, HS_BIG);
+      if (need_z) {
+        sch.laswp(HS_MAT_UR, 0, HS_BIG, 0, P2);
+        sch.trsm_rec(HS_MAT_UR, 0, P2, 0, HS_BIG);
+      }
       for (int a = 0; a < nj; ++a) {
         if (rank[a] < 0) continue;
         LowRankJob<T>& J = jobs[todo[a]];
         LowRank<T>& o = *J.out;
         const int r = rank[a];
         o.ldz = std::max(2, (r + 1) / 2 * 2);
-        if (hipMalloc((void**)&o.Z, sizeof(T) * ((size_t)o.ldz * J.cols + 32)) != hipSuccess ||
+        if ((need_z && hipMalloc((void**)&o.Z, sizeof(T) * ((size_t)o.ldz * J.cols + 32)) != hipSuccess) ||
             hipMalloc((void**)&o.rperm, sizeof(int) * J.rows) != hipSuccess) {
           free_Y();
           hs_set_error(-7, 0, "hipMalloc of a low-rank factor (%d x %d) failed", r, J.cols);
           return -7;
         }
-        if (r > 0) hipLaunchKernelGGL(copy_top_rows_kernel<T>, dim3(J.cols), dim3(256), 0, s, (const T*)J.X, J.ldx, o.Z, o.ldz, r);
+        if (r > 0 && need_z) hipLaunchKernelGGL(copy_top_rows_kernel<T>, dim3(J.cols), dim3(256), 0, s, (const T*)J.X, J.ldx, o.Z, o.ldz, r);
         (void)hipMemcpyAsync(o.rperm, hn[a].rperm, sizeof(int) * J.rows, hipMemcpyDeviceToDevice, s);
         o.Lp = Y[a];
         Y[a] = nullptr;
@@ -263,5 +265,5 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
   return 0;
 }
 
-template int lowrank_compress_batch<double>(LowRankJob<double>*, int, double, double, hipStream_t);
-template int lowrank_compress_batch<cplx>(LowRankJob<cplx>*, int, double, double, hipStream_t);
+template int lowrank_compress_batch<double>(LowRankJob<double>*, int, double, double, hipStream_t, bool);
+template int lowrank_compress_batch<cplx>(LowRankJob<cplx>*, int, double, double, hipStream_t, bool);
