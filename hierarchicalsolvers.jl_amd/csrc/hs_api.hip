@@ -492,7 +492,9 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         if (x.leaf || x.level > swlevel || x.ni < (int)opts.hss_d * 1024 || !x.mine) continue;
         if (x.nb > 0 && !x.compressed) continue;  // |bnd| < swsize: stays dense like in the reference
         x.hssd = true;
-        x.ilv = hss_interleave_perm(h->fidx_host.data() + x.off_fidx, x.ni, x.ni1, n, colptr, rowval, where);
+        static const bool ilv_only = getenv("HS_HSS_ORDER") && getenv("HS_HSS_ORDER")[0] == 'i';  // diagnostics: interleave only
+        x.ilv = ilv_only ? hss_interleave_perm(h->fidx_host.data() + x.off_fidx, x.ni, x.ni1, n, colptr, rowval, where)
+                         : hss_bisect_perm(h->fidx_host.data() + x.off_fidx, x.ni, n, colptr, rowval, where);
       }
     }
     for (auto& L : h->levels) {  // dense fronts first: they are eliminated as one batch, compressed fronts one by one

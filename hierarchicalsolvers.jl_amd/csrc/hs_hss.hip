@@ -454,6 +454,19 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
       if (r > k - (int)H.opt.pad && r < m && k < n) enough = false;
       nd[L[a]].r = r;
     }
+    static const bool verbose = getenv("HS_HSS_VERBOSE") != nullptr;
+    if (verbose) {
+      int mr = 0, mm = 0, full = 0;
+      long long sr = 0;
+      for (int i : L) {
+        mr = std::max(mr, nd[i].r);
+        mm = std::max(mm, nd[i].m);
+        sr += nd[i].r;
+        full += nd[i].r == nd[i].m;
+      }
+      fprintf(stderr, "[hs hss] n=%d k=%d level %d: %d nodes, local size <= %d, rank max %d mean %.1f, %d nodes of full rank%s\n", n, k, lv, nj, mm, mr,
+              (double)sr / nj, full, enough ? "" : "  -> more samples");
+    }
     if (!enough) {
       HSS_HIP(hipStreamSynchronize(s));
       free_lr();

@@ -49,6 +49,86 @@ static std::vector<int64_t> hss_interleave_perm(const int* I, int ni, int ni1, i
   return perm;
 }
 
+// Order of the interior positions by RECURSIVE BISECTION of the graph of A restricted to them (both separator layers and the
+// couplings between them): a set is split into the first half of a breadth-first sweep from a pseudo-peripheral vertex and
+// the rest, exactly where the cluster tree of the HSS matrix splits its index range (at ceil(size/2)), down to sets of
+// `small` vertices.  Every index range of the cluster tree is then a compact patch of the separator: its coupling to the rest
+// goes through the patch boundary only.  (The order the elimination tree hands down lists thin strips: measured on the
+// 32,768 root of Poisson 128^3, leaves of 256 had rank 220.)  perm[new position] = original position.
+static std::vector<int64_t> hss_bisect_perm(const int* I, int ni, int64_t n, const int64_t* colptr, const int64_t* rowval, std::vector<int>& where,
+                                            int small = 32) {
+  std::vector<int64_t> perm;
+  if (ni <= small || !colptr || !rowval || (int64_t)where.size() < n) return perm;
+  for (int e = 0; e < ni; ++e)
+    if (I[e] < 0 || I[e] >= n) return perm;
+  for (int e = 0; e < ni; ++e) where[I[e]] = e;
+  // local adjacency (CSR)
+  std::vector<int> ap(ni + 1, 0), aj;
+  for (int e = 0; e < ni; ++e) {
+    const int64_t g = I[e];
+    for (int64_t a = colptr[g] - 1; a < colptr[g + 1] - 1; ++a) {
+      const int64_t rr = rowval[a] - 1;
+      if (rr < 0 || rr >= n || rr == g) continue;
+      if (where[rr] >= 0) aj.push_back(where[rr]);
+    }
+    ap[e + 1] = (int)aj.size();
+  }
+  for (int e = 0; e < ni; ++e) where[I[e]] = -1;
+  std::vector<int> ord(ni), mark(ni, -1), queue(ni), tmp(ni);
+  for (int e = 0; e < ni; ++e) ord[e] = e;
+  int stamp = 0;
+  // breadth-first order of the vertices ord[lo:hi) (restricted to that set), started at `start`; unreached parts follow
+  auto bfs = [&](int lo, int hi, int start, int inset) {
+    ++stamp;
+    int qh = 0, qt = 0, scan = lo;
+    auto push = [&](int v) {
+      mark[v] = stamp;
+      queue[qt++] = v;
+    };
+    push(start);
+    while (qt < hi - lo) {
+      if (qh == qt) {  // another component
+        while (mark[ord[scan]] == stamp) ++scan;
+        push(ord[scan]);
+      }
+      const int v = queue[qh++];
+      for (int a = ap[v]; a < ap[v + 1]; ++a) {
+        const int w = aj[a];
+        if (tmp[w] == inset && mark[w] != stamp) push(w);
+      }
+    }
+    return qt;
+  };
+  // explicit stack of ranges; tmp[v] = id of the set v currently belongs to
+  std::vector<std::pair<int, int>> st{{0, ni}};
+  std::fill(tmp.begin(), tmp.end(), 0);
+  int nextid = 1;
+  std::vector<int> setid_of_range;
+  while (!st.empty()) {
+    const auto [lo, hi] = st.back();
+    st.pop_back();
+    const int sz = hi - lo;
+    if (sz <= small) continue;
+    const int id = tmp[ord[lo]];
+    // pseudo-peripheral start: last vertex of a sweep from an arbitrary one, twice
+    int start = ord[lo];
+    for (int rep = 0; rep < 2; ++rep) {
+      bfs(lo, hi, start, id);
+      start = queue[sz - 1];
+    }
+    bfs(lo, hi, start, id);
+    for (int t = 0; t < sz; ++t) ord[lo + t] = queue[t];
+    const int mid = lo + (sz + 1) / 2;
+    const int idl = nextid++, idr = nextid++;
+    for (int t = lo; t < mid; ++t) tmp[ord[t]] = idl;
+    for (int t = mid; t < hi; ++t) tmp[ord[t]] = idr;
+    st.push_back({lo, mid});
+    st.push_back({mid, hi});
+  }
+  perm.assign(ord.begin(), ord.end());
+  return perm;
+}
+
 template <class T>
 static void free_hss_nodes(hs_handle* h) {
   for (auto& x : h->nodes) {
