@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--tol", type=float, default=1e-6, help="atol = rtol of the compressed fronts")
     ap.add_argument("--split", type=int, default=0, help="slice width (multiple of 256) in which compressed fronts eliminate their interior block; 0 = off")
     ap.add_argument("--hss-min", type=int, default=0, help="fronts of the compressed levels with at least this many interior DOFs (multiple of 1024) keep D = Aii as an HSS matrix; 0 = dense LU of D")
+    ap.add_argument("--hss-dexp", type=int, default=None, help="orders of magnitude by which the HSS form of D is tighter than --tol (default 2)")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,7 +114,7 @@ def main():
     t_host = time.perf_counter() - t0
     is_c = np.iscomplexobj(Ap.data)
 
-    fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol, split_size=args.split, hss_min=args.hss_min) if args.swlevel != 0 else dict(swlevel=0)
+    fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol, split_size=args.split, hss_min=args.hss_min, hss_dexp=args.hss_dexp) if args.swlevel != 0 else dict(swlevel=0)
     t0 = time.perf_counter()
     S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, **fopts)
     torch.cuda.synchronize(dev)

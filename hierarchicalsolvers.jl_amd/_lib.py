@@ -23,7 +23,7 @@ class hs_options(C.Structure):
     _fields_ = [
         ("swlevel", i64), ("swsize", i64), ("atol", C.c_double), ("rtol", C.c_double), ("c_tol", C.c_double),
         ("leafsize", i64), ("kest", i64), ("stepsize", i64), ("verbose", C.c_uint8),
-        ("keep_schur", C.c_uint8), ("profile", C.c_uint8), ("split", C.c_uint8), ("hss_d", C.c_uint8), ("reserved", C.c_uint8 * 3), ("seed", i64),
+        ("keep_schur", C.c_uint8), ("profile", C.c_uint8), ("split", C.c_uint8), ("hss_d", C.c_uint8), ("hss_dexp", C.c_uint8), ("reserved", C.c_uint8 * 2), ("seed", i64),
     ]
 
 

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -148,21 +149,52 @@ __global__ __launch_bounds__(64) void idx_compose_kernel(const IdxJob* __restric
 // ------------------------------------------------------------------------------------------------
 // host structures
 // ------------------------------------------------------------------------------------------------
+// Device blocks that the sweeps allocate over and over (hundreds of small blocks per hs_hss_ldiv) are recycled through a
+// per-matrix cache: size classes of powers of two, blocks above 64 MiB go straight back to the driver.
+struct BlockCache {
+  std::multimap<size_t, void*> free_;
+  ~BlockCache() {
+    for (auto& kv : free_) (void)hipFree(kv.second);
+  }
+};
 struct Pool {
-  std::vector<void*> v;
+  std::vector<std::pair<void*, size_t>> v;
+  BlockCache* cache = nullptr;
+  Pool() = default;
+  explicit Pool(BlockCache* c) : cache(c) {}
+  Pool(const Pool&) = delete;
+  Pool& operator=(const Pool&) = delete;
   ~Pool() { clear(); }
   void clear() {
-    for (void* p : v) (void)hipFree(p);
+    for (auto& pr : v) {
+      if (cache && pr.second <= ((size_t)64 << 20))
+        cache->free_.insert({pr.second, pr.first});
+      else
+        (void)hipFree(pr.first);
+    }
     v.clear();
   }
   template <class U>
   U* get(size_t count) {
+    size_t bytes = count * sizeof(U) + 512;
+    if (cache) {
+      size_t cls = 1024;
+      while (cls < bytes) cls <<= 1;
+      bytes = cls;
+      auto it = cache->free_.find(bytes);
+      if (it != cache->free_.end()) {
+        void* p = it->second;
+        cache->free_.erase(it);
+        v.push_back({p, bytes});
+        return (U*)p;
+      }
+    }
     void* p = nullptr;
-    if (hipMalloc(&p, count * sizeof(U) + 512) != hipSuccess) {
-      hs_set_error(HS_ERR_NOMEM, 0, "hipMalloc of %zu bytes failed (HSS module)", count * sizeof(U));
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      hs_set_error(HS_ERR_NOMEM, 0, "hipMalloc of %zu bytes failed (HSS module)", bytes);
       throw (int)HS_ERR_NOMEM;
     }
-    v.push_back(p);
+    v.push_back({p, bytes});
     return (U*)p;
   }
 };
@@ -203,7 +235,8 @@ struct HssT {
   hs_hss_options opt;
   std::vector<HNode<T>> nd;
   std::vector<std::vector<int>> lev;
-  Pool keep;  // generators and factors
+  BlockCache cache;  // recycled temporaries of the sweeps (declared first: destroyed last)
+  Pool keep;         // generators and factors
   hipStream_t s = nullptr;
   bool own_stream = false;
   int* perm = nullptr;  // device, n entries (0-based) or null: H ~= A[perm, perm]
@@ -326,7 +359,7 @@ template <class T>
 bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
   const int n = H.n;
   hipStream_t s = H.s;
-  Pool tmp;  // samples and everything else that dies with this attempt
+  Pool tmp(&H.cache);  // samples and everything else that dies with this attempt
   H.keep.clear();
   build_tree(H, n, (int)H.opt.leafsize, (int)H.opt.first_split);
   H.k = k;
@@ -604,7 +637,7 @@ void hss_mul(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q) {
     hss_mul_p(H, X, ldx, Y, ldy, q);
     return;
   }
-  Pool tmp;
+  Pool tmp(&H.cache);
   const int ld = ev(H.n);
   T* Xp = tmp.get<T>((size_t)ld * q);
   T* Yp = tmp.get<T>((size_t)ld * q);
@@ -620,7 +653,7 @@ void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q) {
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
-  Pool tmp;
+  Pool tmp(&H.cache);
   std::vector<RowJob<T>> rows;
   std::vector<GemmProb<T>> gemms;
   if (nd[0].left < 0) {
@@ -744,7 +777,7 @@ void hss_factor(HssT<T>& H) {
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
-  Pool tmp;
+  Pool tmp(&H.cache);
   std::vector<SubJob<T>> subs;
   std::vector<GemmProb<T>> gemms;
   auto t0 = std::chrono::steady_clock::now();
@@ -866,7 +899,7 @@ void hss_ldiv(HssT<T>& H, T* B, int ldb, int q) {
     hss_ldiv_p(H, B, ldb, q);
     return;
   }
-  Pool tmp;
+  Pool tmp(&H.cache);
   const int ld = ev(H.n);
   T* Bp = tmp.get<T>((size_t)ld * q);
   std::vector<RowJob<T>> rows{RowJob<T>{B, ldb, Bp, ld, H.perm, H.n, q, ROW_GATHER}};
@@ -881,7 +914,7 @@ void hss_ldiv_p(HssT<T>& H, T* B, int ldb, int q) {
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
-  Pool tmp;
+  Pool tmp(&H.cache);
   std::vector<RowJob<T>> rows;
   std::vector<GemmProb<T>> gemms;
   std::vector<NodeDesc<T>> descs;

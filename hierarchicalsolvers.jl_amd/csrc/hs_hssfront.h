@@ -6,8 +6,8 @@
 // its children's HSS blocks (:67,126) and so factors an HSS `D` as well; here it is one of these fronts (nb = 0).
 //
 // Per front, on the assembled dense front [Aii Aib; Abi Abb] (LF = [Aii; Abi], UR = Aib, SB = Abb):
-//   A'. H ~= Aii[q, q]  (hs_hss.hip: randomized compression over the INTERLEAVED order q of the two separator layers,
-//       DESIGN.md section 4c) and its ULV-type elimination                                  -- replaces the (2/3) ni^3 LU
+//   A'. H ~= Aii[q, q]  (hs_hss.hip: randomized compression; q = recursive bisection of the graph of A on the interior
+//       DOFs, hss_bisect_perm below) and its ULV-type elimination                           -- replaces the (2/3) ni^3 LU
 //   B.  Aib ~= C_R*Z_R,  Abi ~= C_L*Z_L     randomized row IDs (one batch per level, hs_lowrank_batch.hip)
 //   C'. W = H^-1 * C_R                       HSS solve with rR right-hand sides
 //   E.  S = Abb - C_L*((Z_L*W)*Z_R)          three grouped GEMMs
@@ -174,8 +174,9 @@ static void factor_hss_fronts(hs_handle* h, const int* ids, int count, const Nod
     hs_hss_options o;
     hs_hss_options_default(&o);
     o.leafsize = std::max(32, leaf_env);
-    o.atol = h->opts.atol;
-    o.rtol = h->opts.rtol;
+    const double dsc = std::pow(10.0, -(double)(h->opts.hss_dexp == 0 ? 2 : h->opts.hss_dexp - 1));  // hs_options.hss_dexp
+    o.atol = h->opts.atol * dsc;
+    o.rtol = h->opts.rtol * dsc;
     o.kest = x.last_k > 0 ? x.last_k : (h->opts.kest > 0 ? h->opts.kest : 128);
     o.seed = h->opts.seed + 31 * (int64_t)ids[i];
     hs_hss* H = nullptr;

@@ -63,7 +63,10 @@ typedef struct hs_options {
                          matrix (include/hs_hss.h) instead of a dense LU -- the role of `D::BlockFactorization` over HssMatrix blocks
                          (blockmatrix.jl:121-130, factorization.jl:86-96); the root included, which in the reference receives its
                          children's HSS blocks although it is never flagged (factorization.jl:15,67,126).  Single rank only. */
-  uint8_t reserved[3];
+  uint8_t hss_dexp;   /* tolerance of that HSS form: atol, rtol * 10^-e with e = 2 for hss_dexp = 0 (default) and e = hss_dexp - 1
+                         otherwise (1: the tolerance of the fronts, as the reference does).  D^-1 inherits cond(D) * tol, the low-rank
+                         couplings only tol: measured on Poisson 128^3 the same tolerance for both leaves GMRES unconverged */
+  uint8_t reserved[2];
   int64_t seed;       /* RNG seed of the randomized compression (reference: Random.seed!(123), test/rungmres.jl:7) */
 } hs_options;
 

@@ -1,7 +1,7 @@
 """The reference's scenario (test/rungmres.jl:15-52) on a generated problem: exact factorization, compressed
 factorization, GMRES(30) right-preconditioned by each.  Prints one JSON line per run (diagnostic, not a test).
 
-    python tests/run_gmres_scenario.py poisson3d_64 [swlevel] [tol] [swsize] [hss_min]
+    python tests/run_gmres_scenario.py poisson3d_64 [swlevel] [tol] [swsize] [hss_min] [hss_dexp]
 """
 import json
 import os
@@ -19,6 +19,7 @@ swlevel = int(sys.argv[2]) if len(sys.argv) > 2 else -4
 tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-2
 swsize = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 hss_min = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # > 0: also run the compressed factorization with D kept as HSS
+hss_dexp = int(sys.argv[6]) if len(sys.argv) > 6 else None
 
 A, b, nd = hs.problems.make_problem(name, rhs="randn")
 nd, nd_loc = hs.symfact(nd)
@@ -30,7 +31,7 @@ import torch
 
 runs = [("exact", dict(swlevel=0)), ("compressed", dict(swlevel=swlevel, swsize=swsize, atol=tol, rtol=tol))]
 if hss_min > 0:
-    runs.append(("compressed, HSS D", dict(swlevel=swlevel, swsize=swsize, atol=tol, rtol=tol, hss_min=hss_min)))
+    runs.append(("compressed, HSS D", dict(swlevel=swlevel, swsize=swsize, atol=tol, rtol=tol, hss_min=hss_min, hss_dexp=hss_dexp)))
 for label, kw in runs:
     hs.factor(A, nd, nd_loc, **kw).free()  # warm-up (kernel load, allocator)
     torch.cuda.synchronize()
