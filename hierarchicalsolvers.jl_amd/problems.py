@@ -146,6 +146,8 @@ NAMED = {
     "helmholtz3d_32": ((32, 32, 32), "helmholtz", 512),
     "helmholtz3d_64": ((64, 64, 64), "helmholtz", 4096),
     "helmholtz3d_96": ((96, 96, 96), "helmholtz", 4096),
+    "helmholtz3d_112": ((112, 112, 112), "helmholtz", 4096),  # largest complex 3-D problem whose dense factors fit one MI355X (163 GiB)
+    "helmholtz3d_128": ((128, 128, 128), "helmholtz", 4096),  # 278 GiB of dense complex factors: needs >= 2 GPUs
 }
 
 

@@ -35,7 +35,7 @@ typedef struct hs_hss_options {
   int64_t leafsize;    /* leaves of the cluster tree hold at most this many indices (SolverOptions.leafsize) */
   int64_t first_split; /* > 0: the root splits at this index, bisection_cluster((n1, n)); 0: in the middle */
   double atol, rtol;   /* an off-diagonal block is truncated at max(atol, rtol * |largest pivot of its samples|) */
-  int64_t kest;        /* initial number of samples per side; doubled until every rank <= samples - pad */
+  int64_t kest;        /* initial number of samples per side; doubled until every rank <= 0.8*samples - pad */
   int64_t pad;         /* oversampling (default 8) */
   int64_t seed;
   double level_scale;  /* tolerances of tree level l are multiplied by level_scale^(l-1) (root = level 0): deeper levels are

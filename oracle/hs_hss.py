@@ -100,17 +100,18 @@ def row_id(M, atol, rtol):
     return p, r, T
 
 
-def compress(A, leafsize=64, atol=1e-9, rtol=1e-9, kest=32, first_split=None, seed=123, pad=8, mul=None, mulT=None, level_scale=1.0):
+def compress(A, leafsize=64, atol=1e-9, rtol=1e-9, kest=32, first_split=None, seed=123, pad=8, mul=None, mulT=None, level_scale=1.0, fill=1.0):
     """`randcompress_adaptive`: HSS form of the n x n operator A.  `A` is indexable (`A[np.ix_(i, j)]`); the
     samples come from `mul(X) = A X` and `mulT(X) = A^T X` (plain transpose) when given, else from A itself.
     The sample count doubles until every node's rank is at most k - pad.  `level_scale` < 1 tightens the tolerance of
-    tree level l by level_scale^(l-1) (what the device module does, include/hs_hss.h)."""
+    tree level l by level_scale^(l-1), `fill` < 1 trusts k samples only up to rank fill*k - pad (what the device module does,
+    include/hs_hss.h: 0.5 and 0.8)."""
     n = A.shape[0]
     dtype = np.result_type(A.dtype, np.float64)
     rng = np.random.default_rng(seed)
     k = max(int(kest), 8)
     while True:
-        H = _compress_fixed(A, n, dtype, leafsize, atol, rtol, k, first_split, rng, pad, mul, mulT, level_scale)
+        H = _compress_fixed(A, n, dtype, leafsize, atol, rtol, k, first_split, rng, pad, mul, mulT, level_scale, fill)
         if H is not None:
             return H
         k *= 2
@@ -123,7 +124,7 @@ def _randn(rng, shape, dtype):
     return X.astype(dtype)
 
 
-def _compress_fixed(A, n, dtype, leafsize, atol, rtol, k, first_split, rng, pad, mul, mulT, level_scale=1.0):
+def _compress_fixed(A, n, dtype, leafsize, atol, rtol, k, first_split, rng, pad, mul, mulT, level_scale=1.0, fill=1.0):
     nodes = bisection_cluster(n, leafsize, first_split)
     H = Hss(n, nodes, dtype)
     k = min(k, n)
@@ -151,7 +152,7 @@ def _compress_fixed(A, n, dtype, leafsize, atol, rtol, k, first_split, rng, pad,
             x.m = len(J)
             sc_ = level_scale ** (lv - 1)
             p, r, T = row_id(np.hstack([sr, sc]), atol * sc_, rtol * sc_)
-            if r > k - pad and r < x.m and k < n:
+            if r > int(fill * k) - pad and r < x.m and k < n:
                 return None  # not enough samples for this rank: the caller doubles k
             x.p, x.r, x.T = p, r, T
             x.sk = J[p[:r]]
