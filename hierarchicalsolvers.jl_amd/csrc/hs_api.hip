@@ -1312,6 +1312,45 @@ static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) 
   HS_HIP(hipMemcpy2D(out, (size_t)rows * sizeof(T), base, (size_t)ld * sizeof(T), (size_t)rows * sizeof(T), cols, hipMemcpyDeviceToHost));
 }
 
+// F.S of one node as an HssMatrix: `compress(S[perm, perm], cl, cl; atol, rtol)` with perm = [nd_loc.int; nd_loc.bnd] and
+// cl = bisection_cluster((length(nd_loc.int), length(nd.bnd)); leafsize) (src/factorization.jl:56-57; for a branch the same
+// object comes out of randcompress_adaptive, :109-110).  Needs opts.keep_schur; the HSS matrix keeps S's stored index order.
+extern "C" int hs_node_schur_hss(const hs_handle* F, int64_t node, const hs_hss_options* o, hs_hss** out) {
+  if (!out) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  HS_GUARD(check_device_handle(F); if (node < 0 || node >= hs_num_user_nodes(F)) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+           if (hs_is_split(F, node)) HS_FAIL(HS_ERR_UNSUPPORTED, node, "node %lld is eliminated in slices (hs_options.split)", (long long)node);
+           const NodeH& x = F->nodes[hs_internal_id(F, node)];
+           if (!x.mine) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: node is owned by rank %d", x.owner);
+           if (!F->sb_kept || !F->d_sb) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: Schur complements were not kept (opts.keep_schur)");
+           if (x.nb <= 0 || x.parent < 0) HS_FAIL(HS_ERR_ARGUMENT, node, "ArgumentError: node %lld has no Schur complement", (long long)node);
+           std::vector<int> cm(x.nb);
+           HS_HIP(hipMemcpy(cm.data(), F->d_int + x.off_cmap, sizeof(int) * x.nb, hipMemcpyDeviceToHost));
+           std::vector<int64_t> perm(x.nb);
+           for (int e = 0; e < x.nb; ++e) perm[e] = e;
+           std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return cm[a] < cm[b]; });  // [int_loc; bnd_loc] in the parent's order
+           const NodeH& par = F->nodes[x.parent];
+           int n1 = 0;
+           if (par.level != 0)
+             for (int e = 0; e < x.nb; ++e) n1 += cm[e] >= 0 && cm[e] < par.oni;
+           hs_hss_options oo;
+           hs_hss_options_default(&oo);
+           if (o) {
+             oo = *o;
+           } else {
+             oo.leafsize = F->opts.leafsize;
+             oo.atol = F->opts.atol;
+             oo.rtol = F->opts.rtol;
+             if (F->opts.kest > 0) oo.kest = F->opts.kest;
+             oo.seed = F->opts.seed;
+           }
+           oo.first_split = (n1 > 0 && n1 < x.nb) ? n1 : 0;
+           const void* base = x.ext_sb ? x.ext_sb : (F->is_complex ? (const void*)((const cplx*)F->d_sb + x.off_SB) : (const void*)((const double*)F->d_sb + x.off_SB));
+           const int st = F->is_complex ? hs_hss_compress_ex_z(x.nb, (const double*)base, x.lds, 1, perm.data(), &oo, nullptr, out)
+                                        : hs_hss_compress_ex_d(x.nb, (const double*)base, x.lds, 1, perm.data(), &oo, nullptr, out);
+           if (st != 0) throw HsError{st});
+}
+
 extern "C" int hs_node_export(const hs_handle* F, int64_t node, int which, double* out) {
   HS_GUARD(check_handle(F); if (node < 0 || node >= hs_num_user_nodes(F) || !out) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
            if (hs_is_split(F, node)) HS_FAIL(HS_ERR_UNSUPPORTED, node, "node %lld is eliminated in slices (hs_options.split): it has no single D, L, R", (long long)node);

@@ -182,6 +182,23 @@ class FactorNode:
         out["rperm"] = rp
         return out
 
+    def schur_hss(self, node, **kw):
+        """``F.S`` of one node as an :class:`hss.HssMatrix` (``compress(S[perm,perm], cl, cl)``, factorization.jl:56-57,109-110;
+        needs ``keep_schur``).  Without keywords the factorization's own ``leafsize, atol, rtol, kest, seed`` apply; with any of
+        ``leafsize, atol, rtol, kest, seed, pad, level_scale`` given, the others take the ``SolverOptions`` defaults."""
+        import ctypes as C
+
+        from . import hss
+
+        o = None
+        if kw:
+            d = dict(leafsize=32, atol=1e-6, rtol=1e-6, kest=64, pad=8, seed=123, level_scale=0.5)  # SolverOptions defaults
+            d.update(kw)
+            o = C.byref(_lib.hs_hss_options(d["leafsize"], 0, d["atol"], d["rtol"], d["kest"], d["pad"], d["seed"], d["level_scale"]))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hs_node_schur_hss(self._h, node, o, C.byref(h)))
+        return hss.HssMatrix(h, self.dtype == np.complex128)
+
     def reference_blocks(self, node, with_schur=False):
         """The reference's FactorNode fields of one node, rebuilt from the stored factors:
         ``D = P'LU`` (raw interior block), ``L = Abi*D^-1``, ``R = D^-1*Aib`` (factorization.jl:33-37,69-71)."""

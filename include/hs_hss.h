@@ -78,6 +78,11 @@ int hs_hss_ldiv(hs_hss* H, double* B, int64_t ldb, int64_t nrhs, int where);
 /* wall time of the last compress / factor on the device (seconds, host clock around a synchronised stream) */
 double hs_hss_time(const hs_hss* H, int what); /* 0: compress, 1: factor */
 
+/* `F.S` of one front of a factorization (include/hs_solver.h; needs hs_options.keep_schur) as an HSS matrix:
+ * compress(S[perm,perm], cl, cl; atol, rtol), perm = [nd_loc.int; nd_loc.bnd], cl = bisection_cluster((|nd_loc.int|, |nd.bnd|))
+ * (src/factorization.jl:56-57,109-110).  o == NULL: leafsize, atol, rtol, kest, seed of the factorization's options. */
+int hs_node_schur_hss(const hs_handle* F, int64_t node, const hs_hss_options* o, hs_hss** out);
+
 void hs_hss_free(hs_hss* H);
 
 #ifdef __cplusplus

@@ -55,3 +55,32 @@ def test_hss_fronts_refuse_dense_export(hs):
     F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=2, swsize=8, atol=1e-6, rtol=1e-6, hss_min=1024)
     with pytest.raises(hs.UnsupportedError):
         F.node_blocks(F.nnodes - 1)
+
+
+@pytest.mark.parametrize("name", [((16, 16, 16), dict(kind="poisson", nmax=64)), ((12, 12, 12), dict(kind="helmholtz", nmax=64))])
+def test_schur_complement_as_hss_matrix(hs, name):
+    """`F.S` of a front as an HssMatrix (factorization.jl:56-57,109-110): top-level split at |nd_loc.int|, entries within the
+    tolerance of the stored dense S, hssrank comparable to the oracle's compression of the same S[perm, perm]."""
+    from oracle import hs_hss as HS
+
+    P = prepare(hs, name[0], **name[1])
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0, keep_schur=True)
+    # the two children of the root: largest Schur complements of the tree
+    sizes = [(F.node_info(k)[1], k) for k in range(F.nnodes - 1)]
+    nb, node = max(sizes)
+    S = F.node_blocks(node, with_schur=True)["S"]
+    tol = 1e-6
+    H = F.schur_hss(node, leafsize=16, atol=tol, rtol=tol, kest=16)
+    assert H.shape == (nb, nb)
+    assert np.linalg.norm(H.full() - S) / np.linalg.norm(S) < 100 * tol
+    info1 = H._info(1)
+    n1 = info1["hi"]
+    assert 0 < n1 < nb  # the forced first split [int_loc | bnd_loc]
+    # oracle on the same permuted matrix: perm = positions that go to the parent's int first (read back through the product)
+    e = np.eye(nb)
+    x = np.arange(nb, dtype=float)
+    assert np.allclose(H @ x, H.full() @ x)
+    Ho = HS.compress(S, leafsize=16, atol=tol, rtol=tol, kest=16, level_scale=0.5)
+    assert H.rank <= 2 * HS.hssrank(Ho) + 16 and H.rank > 0
+    b = np.ones(nb, dtype=S.dtype)
+    assert np.linalg.norm(S @ H.ldiv(b) - b) / np.linalg.norm(b) < 1e4 * tol
