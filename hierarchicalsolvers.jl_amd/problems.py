@@ -23,7 +23,7 @@ import scipy.sparse as sp
 
 from .nesteddissection import NDNode, parse_elimtree, serialize_elimtree
 
-__all__ = ["grid_matrix", "grid_nested_dissection", "make_problem", "write_problem", "read_problem", "NAMED"]
+__all__ = ["grid_matrix", "grid_nested_dissection", "graph_nested_dissection", "make_problem", "write_problem", "read_problem", "NAMED"]
 
 
 def _lap1d(n):
@@ -131,6 +131,71 @@ def grid_nested_dissection(shape, nmax):
         return NDNode(_order(ids, cm & ~bmask), _order(ids, bmask), left, right)
 
     return build(tuple([0] * d), shape)
+
+
+def graph_nested_dissection(A, nmax=100):
+    """Nested dissection of a GENERAL sparse matrix from its graph alone (no coordinates): the raw :class:`NDNode` tree in the
+    disjoint-ownership form the reference consumes (``nesteddissection.jl:19-21,105-148``; the generator that made the
+    reference's ``.mat`` trees is not part of it) -- every DOF belongs to exactly one leaf, ``bnd(B)`` = DOFs of ``B`` with a
+    neighbour outside ``B``, a parent's ``int = (bnd(l) | bnd(r)) - bnd(parent)``.
+
+    A set is halved by a breadth-first sweep of its induced subgraph from a pseudo-peripheral vertex (the first half of the
+    sweep against the rest; further components follow the first one), until it holds at most ``nmax`` DOFs.  Global ids are
+    1-based and ascending inside every index vector, like the grid generator's."""
+    from scipy.sparse.csgraph import breadth_first_order
+
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    G = sp.csr_matrix((np.ones(A.nnz, dtype=np.int8), A.indices, A.indptr), shape=A.shape)
+    G = ((G + G.T) > 0).astype(np.int8).tolil()
+    G.setdiag(0)
+    G = sp.csr_matrix(G)
+    G.eliminate_zeros()
+    deg = np.diff(G.indptr)
+
+    def sweep(H, start):
+        """Breadth-first order of every vertex of H: the component of `start` first, then the others."""
+        m = H.shape[0]
+        order = list(breadth_first_order(H, start, directed=False, return_predecessors=False))
+        if len(order) < m:
+            seen = np.zeros(m, dtype=bool)
+            seen[order] = True
+            while len(order) < m:
+                nxt = int(np.flatnonzero(~seen)[0])
+                o = breadth_first_order(H, nxt, directed=False, return_predecessors=False)
+                seen[o] = True
+                order.extend(o)
+        return np.asarray(order, dtype=np.int64)
+
+    def build(V, H):
+        """V: ascending global 0-based ids, H: induced subgraph on V."""
+        inside = np.diff(H.indptr)
+        bmask = deg[V] > inside  # a neighbour outside V
+        if len(V) <= nmax or len(V) < 2:
+            return NDNode(V[~bmask] + 1, V[bmask] + 1)
+        start = 0
+        for _ in range(2):  # pseudo-peripheral vertex: the last vertex of a sweep, twice
+            start = int(breadth_first_order(H, start, directed=False, return_predecessors=False)[-1])
+        order = sweep(H, start)
+        half = (len(V) + 1) // 2
+        sel = np.zeros(len(V), dtype=bool)
+        sel[order[:half]] = True
+        i1, i2 = np.flatnonzero(sel), np.flatnonzero(~sel)
+        H1, H2 = H[i1][:, i1], H[i2][:, i2]
+        left, right = build(V[i1], H1), build(V[i2], H2)
+        cb = np.zeros(len(V), dtype=bool)  # boundary of either child, in V's numbering
+        cb[i1] = deg[V[i1]] > np.diff(H1.indptr)
+        cb[i2] = deg[V[i2]] > np.diff(H2.indptr)
+        return NDNode(V[cb & ~bmask] + 1, V[bmask] + 1, left, right)
+
+    import sys
+
+    lim = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(lim, 10000))
+    try:
+        return build(np.arange(n, dtype=np.int64), G)
+    finally:
+        sys.setrecursionlimit(lim)
 
 
 # name -> (shape, kind, nmax); sizes inferred from the stripped blobs' names (SURVEY.md section 8(d))
