@@ -416,6 +416,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
       Ol[i] = OP + nd[i].lo;
       ldl[i] = ldn;
     }
+  double gscale = 0.0;  // largest sample pivot seen so far (deeper levels): the scale of the matrix's off-diagonal part
   for (int lv = H.nlev - 1; lv >= 1; --lv) {
     const std::vector<int>& L = H.lev[lv];
     const int nj = (int)L.size();
@@ -470,7 +471,10 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
     // (with one tolerance everywhere the sample blocks of the upper levels sit on a noise plateau AT the threshold and the
     // pivoted-LU rank detection reads it as rank: measured 45 instead of 18 at 1e-8 on the test kernel)
     const double lsc = std::pow(H.opt.level_scale, lv - 1);
-    const int st = lowrank_compress_batch<T>(jobs.data(), nj, H.opt.atol * lsc, H.opt.rtol * lsc, s, false);
+    // the relative tolerance refers to the block's own largest pivot, but never to less than the largest one met below: a block
+    // that couples weakly (or not at all) is noise of the children's truncation, and relative to ITSELF noise has full rank
+    const int st = lowrank_compress_batch<T>(jobs.data(), nj, std::max(H.opt.atol, H.opt.rtol * gscale) * lsc, H.opt.rtol * lsc, s, false);
+    for (int a = 0; a < nj; ++a) gscale = std::max(gscale, lr[a].top);
     auto free_lr = [&]() {
       for (auto& q : lr) lowrank_free(q);
     };
@@ -522,7 +526,10 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
         x.ldtt = ev(r);
         x.Tm = H.keep.template get<T>((size_t)x.ldt * r);
         x.Tt = H.keep.template get<T>((size_t)x.ldtt * std::max(nR, 1));
-        subs.push_back(SubJob<T>{lr[a].Lp, lr[a].ldp, nullptr, nullptr, r, 0, nR, r, x.Tm, x.ldt, 0});  // T <- L21
+        if (lr[a].r >= 1)
+          subs.push_back(SubJob<T>{lr[a].Lp, lr[a].ldp, nullptr, nullptr, r, 0, nR, r, x.Tm, x.ldt, 0});  // T <- L21
+        else  // the sample block is zero (the node does not couple to the rest at all): one nominal skeleton position, T = 0 --
+          HSS_HIP(hipMemsetAsync(x.Tm, 0, sizeof(T) * (size_t)x.ldt * r, s));  // the L\U of a zero sketch holds nothing usable
         ij.push_back(IdxJob{x.p, (x.left < 0 && H.perm) ? H.perm + x.lo : Jidx[i], x.lo, r, x.sk});
         maxR = std::max(maxR, nR);
         maxr = std::max(maxr, r);
@@ -542,7 +549,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
           for (int a = 0; a < nj; ++a) {
             const HNode<T>& x = nd[L[a]];
             const int r = x.r, nR = x.m - r;
-            if (nR <= 0 || r <= j0) continue;
+            if (nR <= 0 || r <= j0 || lr[a].r < 1) continue;
             const int j1 = std::min(j0 + 32, r);
             if (r > j1) {
               gp.push_back(GemmProb<T>{x.Tm + (size_t)j1 * x.ldt, lr[a].Lp + j1 + (size_t)j0 * lr[a].ldp, x.Tm + (size_t)j0 * x.ldt, nR, j1 - j0, r - j1, x.ldt,

@@ -9,6 +9,7 @@ struct LowRank {
   int* rperm = nullptr; // rows: pivoted row i of Lp is original row rperm[i]
   T* Z = nullptr;       // r x cols (ld = ldz)
   int rows = 0, cols = 0, k = 0, r = 0, ldp = 0, ldz = 0;
+  double top = 0.0;     // |u_11| of the pivoted sketch: the scale the relative tolerance was applied to
   T* Cd = nullptr;      // optional dense C (rows x r, ld = ldc) in ORIGINAL row order; when set it replaces P'*trap(Lp)
   int ldc = 0;
 };

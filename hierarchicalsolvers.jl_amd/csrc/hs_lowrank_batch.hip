@@ -257,6 +257,7 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
         o.ldp = ldp[a];
         o.k = J.k;
         o.r = r;
+        o.top = (hd.data() + offDg[a])[0];
       }
     }
     LRB_HIP(hipStreamSynchronize(s));  // the temporaries of this pass are released by `g`

@@ -84,14 +84,16 @@ def bisection_cluster(n, leafsize=64, first_split=None):
     return nodes
 
 
-def row_id(M, atol, rtol):
+def row_id(M, atol, rtol, top=None):
     """Row interpolative decomposition M[p[r:]] ~= T M[p[:r]] by a column-pivoted QR of M^T truncated at
-    |R_kk| <= max(atol, rtol |R_11|) (the stopping rule of hs_oracle_lr.pqrfact)."""
+    |R_kk| <= max(atol, rtol |R_11|) (the stopping rule of hs_oracle_lr.pqrfact).  `top` (a one-element list) receives |R_11|."""
     m = M.shape[0]
     if m == 0 or M.shape[1] == 0:
         return np.arange(m), 0, np.zeros((m, 0), M.dtype)
     _, R, p = sla.qr(M.T, mode="economic", pivoting=True, check_finite=False)  # plain transpose on purpose
     d = np.abs(np.diag(R))
+    if top is not None:
+        top[0] = max(top[0], float(d[0]))
     tau = max(atol, rtol * d[0])
     r = int(np.sum(d > tau))
     if r == 0:
@@ -132,7 +134,10 @@ def _compress_fixed(A, n, dtype, leafsize, atol, rtol, k, first_split, rng, pad,
     Yr = mul(Om) if mul is not None else A @ Om
     Yc = mulT(Ps) if mulT is not None else A.T @ Ps
     Sr, Sc, Ot, Pt = {}, {}, {}, {}  # per node: samples on the skeleton rows, compressed test matrices
+    gscale = 0.0  # largest |R_11| of the levels below: floor of the scale the relative tolerance refers to (a block that is
+    # only the noise of its children's truncation has full rank relative to ITSELF); what the device module does
     for lv in range(H.nlevels - 1, 0, -1):
+        tops = [0.0]
         for i in H.level(lv):
             x = nodes[i]
             if x.left < 0:
@@ -151,7 +156,9 @@ def _compress_fixed(A, n, dtype, leafsize, atol, rtol, k, first_split, rng, pad,
                 ol, pl = np.vstack([Ot[x.left], Ot[x.right]]), np.vstack([Pt[x.left], Pt[x.right]])
             x.m = len(J)
             sc_ = level_scale ** (lv - 1)
-            p, r, T = row_id(np.hstack([sr, sc]), atol * sc_, rtol * sc_)
+            p, r, T = row_id(np.hstack([sr, sc]), max(atol, rtol * gscale) * sc_, rtol * sc_, tops)
+            if r == 0 and x.m > 0:  # no coupling at all: one nominal skeleton position, T = 0
+                p, r, T = np.arange(x.m), 1, np.zeros((x.m - 1, 1), dtype)
             if r > int(fill * k) - pad and r < x.m and k < n:
                 return None  # not enough samples for this rank: the caller doubles k
             x.p, x.r, x.T = p, r, T
@@ -159,6 +166,7 @@ def _compress_fixed(A, n, dtype, leafsize, atol, rtol, k, first_split, rng, pad,
             Sr[i], Sc[i] = sr[p[:r]], sc[p[:r]]
             Ot[i] = ol[p[:r]] + T.T @ ol[p[r:]]
             Pt[i] = pl[p[:r]] + T.T @ pl[p[r:]]
+        gscale = max(gscale, tops[0])
     x = nodes[0]
     if x.left < 0:
         x.D = np.array(A[np.ix_(np.arange(n), np.arange(n))], dtype=dtype)

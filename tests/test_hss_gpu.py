@@ -124,3 +124,20 @@ def test_errors(hs):
         hs.hss.compress(np.zeros((3, 4)))
     with pytest.raises(ValueError):
         hs.hss.compress(np.eye(8), leafsize=0)
+
+
+def test_blocks_without_coupling(hs):
+    """Off-diagonal blocks that are exactly (or numerically) zero: a node then keeps one nominal skeleton position with T = 0."""
+    K = kernel_matrix(200)
+    Z = np.zeros((200, 200))
+    A = np.block([[K, Z], [Z, 2.0 * K]])
+    H = hs.hss.compress(A, hs.hss.bisection_cluster((200, 400), leafsize=50), atol=1e-8, rtol=1e-8, kest=32)
+    assert H._info(1)["r"] == 1 and H._info(2)["r"] == 1
+    assert np.linalg.norm(H.full() - A) / np.linalg.norm(A) < 1e-6
+    b = np.arange(400.0)
+    assert np.linalg.norm(H.ldiv(b) - np.linalg.solve(A, b)) / np.linalg.norm(b) < 1e-7
+    D = np.diag(np.linspace(1.0, 3.0, 300))  # every sample block is exactly zero
+    Hd = hs.hss.compress(D, leafsize=50, atol=1e-8, rtol=1e-8, kest=16)
+    assert Hd.rank == 1
+    assert np.allclose(Hd.full(), D)
+    assert np.allclose(Hd.ldiv(b[:300]), b[:300] / np.diag(D))

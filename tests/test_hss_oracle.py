@@ -110,3 +110,17 @@ def test_single_leaf():
     assert np.allclose(HS.hss_full(H), A)
     b = np.arange(20.0)
     assert np.allclose(HS.rs_solve(HS.rs_factor(H), b), np.linalg.solve(A, b))
+
+
+def test_blocks_without_coupling():
+    K = kernel_matrix(200)
+    Z = np.zeros((200, 200))
+    A = np.block([[K, Z], [Z, 2.0 * K]])
+    H = HS.compress(A, leafsize=50, atol=1e-8, rtol=1e-8, kest=32, first_split=200)
+    assert H.nodes[1].r == 1 and H.nodes[2].r == 1  # numerically zero coupling: one nominal skeleton position
+    assert np.linalg.norm(HS.hss_full(H) - A) / np.linalg.norm(A) < 1e-6
+    b = np.arange(400.0)
+    assert np.linalg.norm(HS.rs_solve(HS.rs_factor(H), b) - np.linalg.solve(A, b)) / np.linalg.norm(b) < 1e-7
+    D = np.diag(np.linspace(1.0, 3.0, 300))
+    Hd = HS.compress(D, leafsize=50, atol=1e-8, rtol=1e-8, kest=16)
+    assert HS.hssrank(Hd) == 1 and np.allclose(HS.hss_full(Hd), D)
