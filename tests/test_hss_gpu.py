@@ -141,3 +141,57 @@ def test_blocks_without_coupling(hs):
     assert Hd.rank == 1
     assert np.allclose(Hd.full(), D)
     assert np.allclose(Hd.ldiv(b[:300]), b[:300] / np.diag(D))
+
+
+def test_device_pointer_abi(hs):
+    """`where = 1`: matrix, right-hand sides and results stay in HBM (what a device-resident caller such as the elimination uses)."""
+    import ctypes as C
+
+    import torch
+
+    n, q = 700, 5
+    A = kernel_matrix(n)
+    dA = torch.from_numpy(np.asfortranarray(A).T.copy()).cuda()  # column-major bytes of A
+    L = hs._lib.lib()
+    o = hs._lib.hs_hss_options(64, 0, 1e-8, 1e-8, 32, 8, 123, 0.5)
+    h = C.c_void_p()
+    hs._lib.check(L.hs_hss_compress_ex_d(n, C.c_void_p(dA.data_ptr()), n, 1, None, C.byref(o), None, C.byref(h)))
+    try:
+        X = np.random.default_rng(2).standard_normal((n, q))
+        dX = torch.from_numpy(X.T.copy()).cuda()
+        dY = torch.zeros_like(dX)
+        hs._lib.check(L.hs_hss_mul(h, C.c_void_p(dX.data_ptr()), n, C.c_void_p(dY.data_ptr()), n, q, 1))
+        Y = dY.cpu().numpy().T
+        assert np.linalg.norm(Y - A @ X) / np.linalg.norm(A @ X) < 1e-6
+        hs._lib.check(L.hs_hss_ldiv(h, C.c_void_p(dY.data_ptr()), n, q, 1))  # in place: H^-1 (H X) = X
+        assert np.linalg.norm(dY.cpu().numpy().T - X) / np.linalg.norm(X) < 1e-9
+        assert L.hs_hss_size(h) == n and L.hs_hss_rank(h) > 0 and L.hs_hss_num_nodes(h) >= 3
+        # argument errors come back as codes with a message, never as a crash
+        assert L.hs_hss_mul(h, C.c_void_p(dX.data_ptr()), n, C.c_void_p(dX.data_ptr()), n, q, 1) == hs._lib.HS_ERR_ARGUMENT
+        assert L.hs_hss_ldiv(h, None, n, q, 1) == hs._lib.HS_ERR_ARGUMENT
+        assert L.hs_hss_ldiv(h, C.c_void_p(dY.data_ptr()), n, 0, 1) == 0  # no right-hand side: nothing to do
+        bad = (C.c_int64 * 8)()
+        assert L.hs_hss_node_info(h, 10**6, bad) == hs._lib.HS_ERR_ARGUMENT
+    finally:
+        L.hs_hss_free(h)
+    h2 = C.c_void_p()
+    assert L.hs_hss_compress_ex_d(0, C.c_void_p(dA.data_ptr()), n, 1, None, C.byref(o), None, C.byref(h2)) == hs._lib.HS_ERR_ARGUMENT
+    perm = (C.c_int64 * n)(*([0] * n))  # not a permutation
+    assert L.hs_hss_compress_ex_d(n, C.c_void_p(dA.data_ptr()), n, 1, perm, C.byref(o), None, C.byref(h2)) == hs._lib.HS_ERR_ARGUMENT
+
+
+def test_permuted_matrix(hs):
+    """H ~= A[perm, perm]: a scrambled kernel matrix compresses as well as the ordered one when the permutation is supplied."""
+    n = 600
+    K = kernel_matrix(n)
+    q = np.random.default_rng(7).permutation(n)
+    inv = np.argsort(q)
+    A = K[np.ix_(inv, inv)]  # A[q][:, q] == K
+    H = hs.hss.compress(A, leafsize=50, atol=1e-8, rtol=1e-8, kest=32, perm=q)
+    H0 = hs.hss.compress(K, leafsize=50, atol=1e-8, rtol=1e-8, kest=32)
+    assert H.rank <= H0.rank + 6
+    assert np.linalg.norm(H.full() - A) / np.linalg.norm(A) < 1e-6  # products and solves keep the caller's order
+    b = np.arange(float(n))
+    assert np.linalg.norm(H.ldiv(b) - np.linalg.solve(A, b)) / np.linalg.norm(b) < 1e-7
+    Hbad = hs.hss.compress(A, leafsize=50, atol=1e-8, rtol=1e-8, kest=32)  # without it: ranks close to the block sizes
+    assert Hbad.rank > 2 * H.rank
