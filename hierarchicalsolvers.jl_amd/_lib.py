@@ -67,7 +67,7 @@ EXPORTS = [
     "hs_symbolic_from_elimtree", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_mul", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free", "hs_node_schur_hss",
-    "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak",
+    "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_bisect_perm",
 ]
 
 _lib = None
@@ -213,6 +213,8 @@ def lib():
     L.hs_hss_time.restype = C.c_double
     L.hs_hss_free.argtypes = [vp]
     L.hs_hss_free.restype = None
+    L.hsk_bisect_perm.argtypes = [i64, p_i64, p_i64, i64, p_i64, p_i64]
+    L.hsk_bisect_perm.restype = C.c_int
     L.hsk_mfma_f64_peak.argtypes = [C.c_int, C.c_int]
     L.hsk_mfma_f64_peak.restype = C.c_double
     _lib = L

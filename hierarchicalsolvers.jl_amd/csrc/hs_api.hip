@@ -1312,6 +1312,20 @@ static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) 
   HS_HIP(hipMemcpy2D(out, (size_t)rows * sizeof(T), base, (size_t)ld * sizeof(T), (size_t)rows * sizeof(T), cols, hipMemcpyDeviceToHost));
 }
 
+// Host-only test hook (include/hs_kernels.h): the order in which an HSS interior block lists its DOFs (hs_hssfront.h).
+extern "C" int hsk_bisect_perm(int64_t n, const int64_t* colptr, const int64_t* rowval, int64_t ni, const int64_t* ids, int64_t* perm_out) {
+  if (n <= 0 || ni <= 0 || ni > n || !colptr || !rowval || !ids || !perm_out) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hsk_bisect_perm needs a pattern and an index set");
+    return HS_ERR_ARGUMENT;
+  }
+  HS_GUARD(std::vector<int> I((size_t)ni); for (int64_t e = 0; e < ni; ++e) {
+             if (ids[e] < 1 || ids[e] > n) HS_FAIL(HS_ERR_DIMENSION, e, "BoundsError: index %lld outside 1:%lld", (long long)ids[e], (long long)n);
+             I[(size_t)e] = (int)(ids[e] - 1);
+           } std::vector<int> where((size_t)n, -1);
+           std::vector<int64_t> p = hss_bisect_perm(I.data(), (int)ni, n, colptr, rowval, where);
+           for (int64_t e = 0; e < ni; ++e) perm_out[e] = p.empty() ? e : p[(size_t)e]);
+}
+
 // F.S of one node as an HssMatrix: `compress(S[perm, perm], cl, cl; atol, rtol)` with perm = [nd_loc.int; nd_loc.bnd] and
 // cl = bisection_cluster((length(nd_loc.int), length(nd.bnd)); leafsize) (src/factorization.jl:56-57; for a branch the same
 // object comes out of randcompress_adaptive, :109-110).  Needs opts.keep_schur; the HSS matrix keeps S's stored index order.

@@ -177,7 +177,11 @@ static void factor_hss_fronts(hs_handle* h, const int* ids, int count, const Nod
     const double dsc = std::pow(10.0, -(double)(h->opts.hss_dexp == 0 ? 2 : h->opts.hss_dexp - 1));  // hs_options.hss_dexp
     o.atol = h->opts.atol * dsc;
     o.rtol = h->opts.rtol * dsc;
-    o.kest = x.last_k > 0 ? x.last_k : (h->opts.kest > 0 ? h->opts.kest : 128);
+    // samples to start from: what the previous factorization of this front ended with, else opts.kest, else a guess from the size (the
+    // HSS rank of a 2-D separator block grows like its perimeter, ~ sqrt(ni)): every doubling repeats the 4*ni^2*k flops of the samples
+    int64_t k0 = 128;
+    while (k0 < 4.0 * std::sqrt((double)x.ni)) k0 *= 2;
+    o.kest = x.last_k > 0 ? x.last_k : (h->opts.kest > 0 ? h->opts.kest : k0);
     o.seed = h->opts.seed + 31 * (int64_t)ids[i];
     hs_hss* H = nullptr;
     const int64_t* q = x.ilv.empty() ? nullptr : x.ilv.data();

@@ -40,6 +40,11 @@ int hsk_lowrank_d(int64_t rows, int64_t cols, const double* X, double atol, doub
 int hsk_lowrank_z(int64_t rows, int64_t cols, const double* X, double atol, double rtol, int64_t kinit, int64_t seed,
                   int64_t* r_out, double* Cout, double* Zout, int64_t cap);
 
+/* Host-only: the order in which the HSS form of a front's interior block lists its DOFs (hs_options.hss_d): recursive bisection of
+ * the graph of A (1-based CSC pattern colptr / rowval of the n x n matrix) restricted to the ni DOFs `ids` (1-based), split where the
+ * HSS cluster tree splits its index range.  perm_out[new position] = position in `ids` (0-based). */
+int hsk_bisect_perm(int64_t n, const int64_t* colptr, const int64_t* rowval, int64_t ni, const int64_t* ids, int64_t* perm_out);
+
 /* Measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on every CU (roofline denominator). */
 double hsk_mfma_f64_peak(int waves_per_simd, int iters);
 

@@ -6,6 +6,7 @@ import re
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
 from conftest import ROOT, have_gpu
@@ -175,3 +176,37 @@ def test_native_symbolic_layer_errors():
     ni2[root] += 1
     with pytest.raises(hs.DimensionMismatch):
         hs.native_symbolic(f, ls, rs, ni2, inter2, nb, bound)
+
+
+def test_hss_block_order_is_a_compact_bisection(hs):
+    """`hsk_bisect_perm` (host only): the order of an HSS interior block is a permutation whose index ranges are compact patches.
+    Two coupled layers of a 64 x 64 grid, handed over in strip order as the elimination tree does."""
+    N = 64
+    A = hs.problems.grid_matrix((N, N, 2), "poisson")  # x fastest, then y, then the layer
+    n = A.shape[0]
+    colptr = np.ascontiguousarray(A.indptr, dtype=np.int64) + 1
+    rowval = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    perm = np.zeros(n, dtype=np.int64)
+    L = hs._lib.lib()
+    hs._lib.check(L.hsk_bisect_perm(n, colptr.ctypes.data_as(hs._lib.p_i64), rowval.ctypes.data_as(hs._lib.p_i64), n,
+                                    ids.ctypes.data_as(hs._lib.p_i64), perm.ctypes.data_as(hs._lib.p_i64)))
+    assert sorted(perm.tolist()) == list(range(n))
+    pos = np.empty(n, dtype=np.int64)
+    pos[perm] = np.arange(n)
+    G = sp.csr_matrix(A)
+
+    def mean_boundary(order_pos, leaf):
+        cnt = []
+        for lo in range(0, n, leaf):
+            v = np.flatnonzero((order_pos >= lo) & (order_pos < lo + leaf))
+            nb = G[v].indices
+            out = (order_pos[nb] // leaf) != lo // leaf
+            rows = np.repeat(np.arange(len(v)), np.diff(G[v].indptr))
+            cnt.append(len(np.unique(rows[out])))
+        return float(np.mean(cnt))
+
+    # leaves of 256 positions: in the handed-down order they are 4 grid lines (every DOF has a neighbour outside), bisected they are patches
+    assert mean_boundary(np.arange(n), 256) > 250
+    assert mean_boundary(pos, 256) < 110
+    assert L.hsk_bisect_perm(n, None, None, n, ids.ctypes.data_as(hs._lib.p_i64), perm.ctypes.data_as(hs._lib.p_i64)) == hs._lib.HS_ERR_ARGUMENT
