@@ -150,7 +150,8 @@ int hs_pack_bnd(const hs_handle* F, int64_t node, const void* d_b, void* d_buf, 
 int hs_unpack_bnd(const hs_handle* F, int64_t node, void* d_b, const void* d_buf, void* stream); /* b[bnd_j] = buf[j] */
 int hs_extract_owned(const hs_handle* F, const void* d_b, void* d_out, void* stream); /* out[int(mine)] = b[int(mine)] */
 
-int64_t hs_maxrank(const hs_handle* F); /* factornode.jl:49-57; 0 for the dense path */
+int64_t hs_maxrank(const hs_handle* F); /* factornode.jl:49-57: largest of rank(L), rank(R) and the HSS ranks the factorization
+                                           holds (hssrank of the interior blocks kept as HSS, hs_options.hss_d); 0 for the dense path */
 /* ranks of one front's Gauss transforms (0 = dense); returns 1 if the front is compressed, 0 if not, <0 on error */
 int hs_node_ranks(const hs_handle* F, int64_t node, int64_t* rank_L, int64_t* rank_R);
 int hs_is_complex(const hs_handle* F);  /* eltype(F) == ComplexF64 */
