@@ -299,3 +299,96 @@ def rs_solve(F, B):
                 rl = nodes[x.left].r
                 xs[x.left], xs[x.right] = loc[:rl], loc[rl:]
     return X.reshape(B.shape)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# access to parts of an HSS matrix: what the matrix-free assembly of a parent front needs from its children's S
+# (src/factorization.jl:126-140 reads `S.A11`, `S.A22`, `generators(S.A11)`, `S.B12`, `S.B21`)
+# --------------------------------------------------------------------------------------------------------------
+def _local_basis(x):
+    """U_i = P^T [I; T] ((m) x r) of a non-root node."""
+    U = np.zeros((x.m, x.r), dtype=x.T.dtype)
+    U[x.p[: x.r]] = np.eye(x.r, dtype=x.T.dtype)
+    U[x.p[x.r :]] = x.T
+    return U
+
+
+def basis_rows(H, i, idx):
+    """Rows `idx` (global indices inside node i's range, ascending or not) of the EXPANDED nested basis of node i."""
+    x = H.nodes[i]
+    idx = np.asarray(idx, dtype=np.int64)
+    if x.left < 0:
+        return _local_basis(x)[idx - x.lo]
+    l, r = H.nodes[x.left], H.nodes[x.right]
+    inl = idx < l.hi
+    W = np.zeros((len(idx), l.r + r.r), dtype=H.dtype)
+    if inl.any():
+        W[inl, : l.r] = basis_rows(H, x.left, idx[inl])
+    if (~inl).any():
+        W[~inl, l.r :] = basis_rows(H, x.right, idx[~inl])
+    return W @ _local_basis(x) if i != 0 else W
+
+
+def hss_getindex(H, I, J):
+    """H[I, J] for index arrays (0-based): the entry access `randcompress_adaptive` asks of its operator."""
+    I, J = np.asarray(I, dtype=np.int64), np.asarray(J, dtype=np.int64)
+    out = np.zeros((len(I), len(J)), dtype=H.dtype)
+
+    def rec(i, ri, rj):  # ri / rj: positions into I / J that fall into node i's range
+        x = H.nodes[i]
+        if len(ri) == 0 or len(rj) == 0:
+            return
+        if x.left < 0:
+            out[np.ix_(ri, rj)] = x.D[np.ix_(I[ri] - x.lo, J[rj] - x.lo)]
+            return
+        mid = H.nodes[x.left].hi
+        il, ir = ri[I[ri] < mid], ri[I[ri] >= mid]
+        jl, jr = rj[J[rj] < mid], rj[J[rj] >= mid]
+        rec(x.left, il, jl)
+        rec(x.right, ir, jr)
+        if len(il) and len(jr):
+            out[np.ix_(il, jr)] = basis_rows(H, x.left, I[il]) @ x.B12 @ basis_rows(H, x.right, J[jr]).T
+        if len(ir) and len(jl):
+            out[np.ix_(ir, jl)] = basis_rows(H, x.right, I[ir]) @ x.B21 @ basis_rows(H, x.left, J[jl]).T
+
+    rec(0, np.arange(len(I)), np.arange(len(J)))
+    return out
+
+
+def hss_child(H, which):
+    """`H.A11` (which = 0) or `H.A22` (which = 1): the diagonal block of the top-level split as an HSS matrix of its own."""
+    root = H.nodes[0]
+    if root.left < 0:
+        raise ValueError("One of the Schur complements turned into a leaf. Aborting.")  # factorization.jl:164
+    top = root.left if which == 0 else root.right
+    off = H.nodes[top].lo
+    ids, stack = [], [top]
+    while stack:  # breadth-first renumbering of the subtree
+        nxt = []
+        for i in stack:
+            ids.append(i)
+            if H.nodes[i].left >= 0:
+                nxt += [H.nodes[i].left, H.nodes[i].right]
+        stack = nxt
+    new = {old: k for k, old in enumerate(ids)}
+    nodes = []
+    for old in ids:
+        x = H.nodes[old]
+        y = HssNode(x.lo - off, x.hi - off, x.level - 1, new.get(x.parent, -1))
+        y.left, y.right = (new[x.left], new[x.right]) if x.left >= 0 else (-1, -1)
+        y.m, y.D, y.B12, y.B21 = x.m, x.D, x.B12, x.B21
+        if old != top:
+            y.p, y.r, y.T = x.p, x.r, x.T
+            y.sk = None if x.sk is None else x.sk - off
+        nodes.append(y)
+    return Hss(H.nodes[top].hi - off, nodes, H.dtype)
+
+
+def hss_offdiag(H):
+    """The two off-diagonal blocks of the top-level split in low-rank form: A12 = U1 B12 V2^T, A21 = U2 B21 V1^T with the
+    expanded bases (U = V here).  Returns (U1, B12, U2, B21)."""
+    root = H.nodes[0]
+    l, r = H.nodes[root.left], H.nodes[root.right]
+    U1 = basis_rows(H, root.left, np.arange(l.lo, l.hi))
+    U2 = basis_rows(H, root.right, np.arange(r.lo, r.hi))
+    return U1, root.B12, U2, root.B21

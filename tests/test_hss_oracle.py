@@ -124,3 +124,22 @@ def test_blocks_without_coupling():
     D = np.diag(np.linspace(1.0, 3.0, 300))
     Hd = HS.compress(D, leafsize=50, atol=1e-8, rtol=1e-8, kest=16)
     assert HS.hssrank(Hd) == 1 and np.allclose(HS.hss_full(Hd), D)
+
+
+def test_entry_access_children_and_offdiagonal_generators():
+    n = 420
+    A = kernel_matrix(n, seed=5)
+    H = HS.compress(A, leafsize=40, atol=1e-9, rtol=1e-9, kest=32, first_split=150)
+    Fh = HS.hss_full(H)
+    rng = np.random.default_rng(3)
+    I, J = rng.permutation(n)[:90], rng.permutation(n)[:70]
+    assert np.allclose(HS.hss_getindex(H, I, J), Fh[np.ix_(I, J)], atol=1e-12 * np.abs(Fh).max())
+    H11, H22 = HS.hss_child(H, 0), HS.hss_child(H, 1)
+    assert H11.n == 150 and H22.n == n - 150
+    assert np.allclose(HS.hss_full(H11), Fh[:150, :150]) and np.allclose(HS.hss_full(H22), Fh[150:, 150:])
+    x = rng.standard_normal(150)
+    assert np.allclose(HS.rs_solve(HS.rs_factor(H11), x), np.linalg.solve(Fh[:150, :150], x))
+    U1, B12, U2, B21 = HS.hss_offdiag(H)
+    assert np.allclose(U1 @ B12 @ U2.T, Fh[:150, 150:]) and np.allclose(U2 @ B21 @ U1.T, Fh[150:, :150])
+    with pytest.raises(ValueError, match="turned into a leaf"):
+        HS.hss_child(HS.compress(kernel_matrix(20), leafsize=64), 0)
