@@ -352,11 +352,24 @@ void build_tree(HssT<T>& H, int n, int leafsize, int first_split) {
   for (int i = 0; i < (int)H.nd.size(); ++i) H.lev[H.nd[i].level].push_back(i);
 }
 
+// Optional low-rank update of the matrix being compressed: A = B - C*M*Z with thin C (n x r1), small M (r1 x r2), thin Z (r2 x n).
+// The Schur complement of a compressed front is such an operator -- `S = Abb - Abi*R` with a low-rank `R`, seen through products
+// (`_sample_schur!`, src/factorization.jl:238-244) and entries (`_getindex_schur`, :246-249) -- and is compressed WITHOUT being formed:
+// the samples take three thin GEMMs more, every gathered block B[I, J] is corrected by (C[I, :]*M)*Z[:, J].
+template <class T>
+struct Lru {
+  const T* C = nullptr;
+  const T* M = nullptr;
+  const T* Z = nullptr;
+  int ldc = 0, ldm = 0, ldz = 0, r1 = 0, r2 = 0;
+  bool on() const { return C && M && Z && r1 > 0 && r2 > 0; }
+};
+
 // ------------------------------------------------------------------------------------------------
 // compression with k samples per side; returns false when some rank came too close to k (caller doubles k)
 // ------------------------------------------------------------------------------------------------
 template <class T>
-bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
+bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = Lru<T>()) {
   const int n = H.n;
   hipStream_t s = H.s;
   Pool tmp(&H.cache);  // samples and everything else that dies with this attempt
@@ -368,13 +381,53 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
   std::vector<SubJob<T>> subs;
   std::vector<RowJob<T>> rows;
   std::vector<GemmProb<T>> gemms;
+  T* MT = nullptr;  // M^T for the transposed gathers
+  if (lru.on()) {
+    MT = tmp.get<T>((size_t)ev(lru.r2) * lru.r1);
+    std::vector<SubJob<T>> one{SubJob<T>{lru.M, lru.ldm, nullptr, nullptr, 0, 0, lru.r1, lru.r2, MT, ev(lru.r2), 1}};
+    run_subs(tmp, one, s);
+  }
+  // blocks of A by index lists (the jobs in `subs` all read A): B's entries, minus the low-rank update's
+  auto gather_A = [&]() {
+    std::vector<SubJob<T>> jobs = subs;
+    run_subs(tmp, subs, s);
+    if (!lru.on()) return;
+    std::vector<SubJob<T>> pieces;
+    std::vector<GemmProb<T>> g1, g2;
+    for (const SubJob<T>& j : jobs) {
+      if (j.rows <= 0 || j.cols <= 0) continue;
+      const int r1 = lru.r1, r2 = lru.r2;
+      if (!j.trans) {
+        T* Cg = tmp.get<T>((size_t)ev(j.rows) * r1);
+        T* Zg = tmp.get<T>((size_t)ev(r2) * j.cols);
+        T* T1 = tmp.get<T>((size_t)ev(j.rows) * r2);
+        HSS_HIP(hipMemsetAsync(T1, 0, sizeof(T) * (size_t)ev(j.rows) * r2, s));
+        pieces.push_back(SubJob<T>{lru.C, lru.ldc, j.ri, nullptr, j.r0, 0, j.rows, r1, Cg, ev(j.rows), 0});
+        pieces.push_back(SubJob<T>{lru.Z, lru.ldz, nullptr, j.ci, 0, j.c0, r2, j.cols, Zg, ev(r2), 0});
+        g1.push_back(GemmProb<T>{Cg, lru.M, T1, j.rows, r2, r1, ev(j.rows), lru.ldm, ev(j.rows)});
+        g2.push_back(GemmProb<T>{T1, Zg, j.out, j.rows, j.cols, r2, ev(j.rows), ev(r2), j.ldo});
+      } else {  // out is cols x rows:  out -= Z[:, J]^T * (M^T * C[I, :]^T)
+        T* CgT = tmp.get<T>((size_t)ev(r1) * j.rows);
+        T* ZgT = tmp.get<T>((size_t)ev(j.cols) * r2);
+        T* T1T = tmp.get<T>((size_t)ev(r2) * j.rows);
+        HSS_HIP(hipMemsetAsync(T1T, 0, sizeof(T) * (size_t)ev(r2) * j.rows, s));
+        pieces.push_back(SubJob<T>{lru.C, lru.ldc, j.ri, nullptr, j.r0, 0, j.rows, r1, CgT, ev(r1), 1});
+        pieces.push_back(SubJob<T>{lru.Z, lru.ldz, nullptr, j.ci, 0, j.c0, r2, j.cols, ZgT, ev(j.cols), 1});
+        g1.push_back(GemmProb<T>{MT, CgT, T1T, r2, j.rows, r1, ev(r2), ev(r1), ev(r2)});
+        g2.push_back(GemmProb<T>{ZgT, T1T, j.out, j.cols, j.rows, r2, ev(j.cols), ev(r2), j.ldo});
+      }
+    }
+    run_subs(tmp, pieces, s);
+    run_gemms(tmp, g1, 0, s);
+    run_gemms(tmp, g2, 1, s);
+  };
   if (nd[0].left < 0) {  // a single leaf: H = D
     HNode<T>& x = nd[0];
     x.m = n;
     x.ldd = ev(n);
     x.D = H.keep.template get<T>((size_t)x.ldd * n);
     subs.push_back(SubJob<T>{A, lda, H.perm, H.perm, 0, 0, n, n, x.D, x.ldd, 0});
-    run_subs(tmp, subs, s);
+    gather_A();
     HSS_HIP(hipStreamSynchronize(s));
     return true;
   }
@@ -397,6 +450,26 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
   gemms.push_back(GemmProb<T>{A, OPs, Ys, n, k, n, lda, ldn, ldn});
   gemms.push_back(GemmProb<T>{PsT, A, W, k, n, n, ldk, lda, ldk});
   run_gemms(tmp, gemms, 0, s);
+  if (lru.on()) {  // Ys -= C*(M*(Z*OPs)),  W -= ((PsT*C)*M)*Z
+    const int r1 = lru.r1, r2 = lru.r2;
+    T* t1 = tmp.get<T>((size_t)ev(r2) * k);
+    T* t2 = tmp.get<T>((size_t)ev(r1) * k);
+    T* u1 = tmp.get<T>((size_t)ldk * r1);
+    T* u2 = tmp.get<T>((size_t)ldk * r2);
+    HSS_HIP(hipMemsetAsync(t1, 0, sizeof(T) * (size_t)ev(r2) * k, s));
+    HSS_HIP(hipMemsetAsync(t2, 0, sizeof(T) * (size_t)ev(r1) * k, s));
+    HSS_HIP(hipMemsetAsync(u1, 0, sizeof(T) * (size_t)ldk * r1, s));
+    HSS_HIP(hipMemsetAsync(u2, 0, sizeof(T) * (size_t)ldk * r2, s));
+    gemms.push_back(GemmProb<T>{lru.Z, OPs, t1, r2, k, n, lru.ldz, ldn, ev(r2)});
+    gemms.push_back(GemmProb<T>{PsT, lru.C, u1, k, r1, n, ldk, lru.ldc, ldk});
+    run_gemms(tmp, gemms, 0, s);
+    gemms.push_back(GemmProb<T>{lru.M, t1, t2, r1, k, r2, lru.ldm, ev(r2), ev(r1)});
+    gemms.push_back(GemmProb<T>{u1, lru.M, u2, k, r2, r1, ldk, lru.ldm, ldk});
+    run_gemms(tmp, gemms, 0, s);
+    gemms.push_back(GemmProb<T>{lru.C, t2, Ys, n, k, r1, lru.ldc, ev(r1), ldn});
+    gemms.push_back(GemmProb<T>{u2, lru.Z, W, k, n, r2, ldk, lru.ldz, ldk});
+    run_gemms(tmp, gemms, 1, s);
+  }
   subs.push_back(SubJob<T>{W, ldk, nullptr, nullptr, 0, 0, k, n, Ys + (size_t)ldn * k, ldn, 1});
   run_subs(tmp, subs, s);
   if (H.perm) {
@@ -456,7 +529,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
         gemms.push_back(GemmProb<T>{B12T[i], Oi + ck, Yi + rl + ck, rr, k, rl, x.ld21, ld, ld});  // Sc_r -= B12^T * Ps~_l
       }
     }
-    run_subs(tmp, subs, s);
+    gather_A();
     run_gemms(tmp, gemms, 1, s);
     // ---- b. row IDs of the sample blocks [Sr | Sc] (read in place: without Z the ID leaves its input alone) -----------------
     std::vector<LowRank<T>> lr(nj);
@@ -643,7 +716,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k) {
     x.B21 = H.keep.template get<T>((size_t)x.ld21 * l.r);
     subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, l.r, r.r, x.B12, x.ld12, 0});
     subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, r.r, l.r, x.B21, x.ld21, 0});
-    run_subs(tmp, subs, s);
+    gather_A();
   }
   HSS_HIP(hipStreamSynchronize(s));
   return true;
@@ -1009,8 +1082,15 @@ void hss_ldiv_p(HssT<T>& H, T* B, int ldb, int q) {
   HSS_HIP(hipStreamSynchronize(s));
 }
 
+struct LruArgs {  // host-side description of the optional update  - C*M*Z  (pointers in the memory space `where` names)
+  const void* C = nullptr;
+  const void* M = nullptr;
+  const void* Z = nullptr;
+  int64_t ldc = 0, ldm = 0, ldz = 0, r1 = 0, r2 = 0;
+};
 template <class T>
-HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_hss_options* o, const int64_t* perm = nullptr, void* stream = nullptr) {
+HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_hss_options* o, const int64_t* perm = nullptr, void* stream = nullptr,
+                       const LruArgs* la = nullptr) {
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
     hs_set_error(HS_ERR_DEVICE, 0, "no HIP device available (the HSS module has no CPU fallback)");
@@ -1061,10 +1141,34 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
     HSS_HIP(hipMemcpy2D(d, sizeof(T) * ld, A, sizeof(T) * lda, sizeof(T) * n, n, hipMemcpyHostToDevice));
     dA = d;
   }
+  Lru<T> lru;
+  if (la && la->r1 > 0 && la->r2 > 0) {
+    if (!la->C || !la->M || !la->Z || la->ldc < n || la->ldm < la->r1 || la->ldz < la->r2 || la->r1 > n || la->r2 > n) {
+      hs_set_error(HS_ERR_DIMENSION, 0, "DimensionMismatch: the low-rank update needs C (n x r1), M (r1 x r2), Z (r2 x n)");
+      throw (int)HS_ERR_DIMENSION;
+    }
+    lru.r1 = (int)la->r1;
+    lru.r2 = (int)la->r2;
+    if (where == 0) {
+      T* dC = in.get<T>((size_t)ev((int)n) * la->r1);
+      T* dM = in.get<T>((size_t)ev(lru.r1) * la->r2);
+      T* dZ = in.get<T>((size_t)ev(lru.r2) * n);
+      HSS_HIP(hipMemcpy2D(dC, sizeof(T) * ev((int)n), la->C, sizeof(T) * la->ldc, sizeof(T) * n, la->r1, hipMemcpyHostToDevice));
+      HSS_HIP(hipMemcpy2D(dM, sizeof(T) * ev(lru.r1), la->M, sizeof(T) * la->ldm, sizeof(T) * la->r1, la->r2, hipMemcpyHostToDevice));
+      HSS_HIP(hipMemcpy2D(dZ, sizeof(T) * ev(lru.r2), la->Z, sizeof(T) * la->ldz, sizeof(T) * la->r2, n, hipMemcpyHostToDevice));
+      lru.C = dC; lru.ldc = ev((int)n);
+      lru.M = dM; lru.ldm = ev(lru.r1);
+      lru.Z = dZ; lru.ldz = ev(lru.r2);
+    } else {
+      lru.C = (const T*)la->C; lru.ldc = (int)la->ldc;
+      lru.M = (const T*)la->M; lru.ldm = (int)la->ldm;
+      lru.Z = (const T*)la->Z; lru.ldz = (int)la->ldz;
+    }
+  }
   auto t0 = std::chrono::steady_clock::now();
   int k = (int)std::min<int64_t>(std::max<int64_t>(opt.kest > 0 ? opt.kest : 64, 8), n);
   for (;;) {
-    if (compress_fixed<T>(*H, dA, ld, k)) break;
+    if (compress_fixed<T>(*H, dA, ld, k, lru)) break;
     if (k >= n) break;
     k = (int)std::min<int64_t>(2 * (int64_t)k, n);
   }
@@ -1127,6 +1231,23 @@ extern "C" int hs_hss_compress_ex_z(int64_t n, const double* A, int64_t lda, int
   if (!out) return HS_ERR_ARGUMENT;
   *out = nullptr;
   HSS_GUARD(*out = new hs_hss{1, compress_impl<cplx>(n, (const cplx*)A, lda, where, o, perm, stream)});
+}
+
+// H ~= (B - C*M*Z)[perm, perm] without forming the matrix: the Schur complement of a compressed front as the reference samples it
+// (`_schur_complement`, `_sample_schur!`, `_getindex_schur`, src/factorization.jl:228-249) under `randcompress_adaptive` (:110)
+extern "C" int hs_hss_compress_lru_d(int64_t n, const double* B, int64_t ldb, const double* C_, int64_t ldc, const double* M, int64_t ldm, const double* Z,
+                                     int64_t ldz, int64_t r1, int64_t r2, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out) {
+  if (!out) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  LruArgs la{C_, M, Z, ldc, ldm, ldz, r1, r2};
+  HSS_GUARD(*out = new hs_hss{0, compress_impl<double>(n, B, ldb, where, o, perm, stream, &la)});
+}
+extern "C" int hs_hss_compress_lru_z(int64_t n, const double* B, int64_t ldb, const double* C_, int64_t ldc, const double* M, int64_t ldm, const double* Z,
+                                     int64_t ldz, int64_t r1, int64_t r2, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out) {
+  if (!out) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  LruArgs la{C_, M, Z, ldc, ldm, ldz, r1, r2};
+  HSS_GUARD(*out = new hs_hss{1, compress_impl<cplx>(n, (const cplx*)B, ldb, where, o, perm, stream, &la)});
 }
 
 extern "C" int hs_hss_set_stream(hs_hss* H, void* stream) {

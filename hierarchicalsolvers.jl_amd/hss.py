@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["HssMatrix", "compress", "randcompress_adaptive", "hssrank", "bisection_cluster"]
+__all__ = ["HssMatrix", "compress", "compress_lowrank_update", "randcompress_adaptive", "hssrank", "bisection_cluster"]
 
 
 def bisection_cluster(n, leafsize=64):
@@ -146,6 +146,32 @@ def compress(A, cl=None, *, leafsize=64, atol=1e-6, rtol=1e-6, kest=64, seed=123
             raise _lib.DimensionMismatch(f"perm has {perm.shape} entries, the matrix has {n} rows")
         pp = perm.ctypes.data_as(_lib.p_i64)
     _lib.check(f(n, Af.ctypes.data_as(C.c_void_p), n, 0, pp, C.byref(o), None, C.byref(h)))
+    return HssMatrix(h, is_c)
+
+
+def compress_lowrank_update(B, Cm, M, Z, cl=None, *, leafsize=64, atol=1e-6, rtol=1e-6, kest=64, seed=123, pad=8, level_scale=0.5, perm=None):
+    """HSS form of the operator ``B - Cm @ M @ Z`` without forming it: the Schur complement ``S = Abb - Abi*R`` of a compressed front
+    as the reference compresses it, from products and entries (``_schur_complement`` / ``_sample_schur!`` / ``_getindex_schur``,
+    factorization.jl:228-249, under ``randcompress_adaptive``, :110)."""
+    B, Cm, M, Z = (np.asarray(a) for a in (B, Cm, M, Z))
+    n = B.shape[0]
+    if B.shape != (n, n) or Cm.shape[0] != n or Z.shape[1] != n or M.shape != (Cm.shape[1], Z.shape[0]):
+        raise _lib.DimensionMismatch(f"B {B.shape}, C {Cm.shape}, M {M.shape}, Z {Z.shape} do not form B - C*M*Z")
+    first, n_cl, leaf = cl if cl is not None else (0, n, leafsize)
+    is_c = any(np.iscomplexobj(a) for a in (B, Cm, M, Z))
+    dt = np.complex128 if is_c else np.float64
+    Bf, Cf, Mf, Zf = (np.asfortranarray(a.astype(dt)) for a in (B, Cm, M, Z))
+    o = _lib.hs_hss_options(leaf, first, atol, rtol, kest, pad, seed, level_scale)
+    h = C.c_void_p()
+    L = _lib.lib()
+    f = L.hs_hss_compress_lru_z if is_c else L.hs_hss_compress_lru_d
+    pp = None
+    if perm is not None:
+        perm = np.ascontiguousarray(perm, dtype=np.int64)
+        pp = perm.ctypes.data_as(_lib.p_i64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    r1, r2 = M.shape
+    _lib.check(f(n, vp(Bf), n, vp(Cf), n, vp(Mf), max(r1, 1), vp(Zf), max(r2, 1), r1, r2, 0, pp, C.byref(o), None, C.byref(h)))
     return HssMatrix(h, is_c)
 
 

@@ -56,6 +56,15 @@ int hs_hss_compress_z(int64_t n, const double* A, int64_t lda, int where, const 
 int hs_hss_compress_ex_d(int64_t n, const double* A, int64_t lda, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
 int hs_hss_compress_ex_z(int64_t n, const double* A, int64_t lda, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
 
+/* The same for an operator that is never formed: H ~= (B - C*M*Z)[perm, perm] with dense B (n x n), thin C (n x r1), small M (r1 x r2)
+ * and thin Z (r2 x n) -- the Schur complement `S = Abb - Abi*R` of a compressed front as the reference compresses it, through products
+ * (`_sample_schur!`, src/factorization.jl:238-244) and entries (`_getindex_schur`, :246-249) under `randcompress_adaptive` (:110).
+ * r1 = 0 or r2 = 0: no update (the plain compression of B). */
+int hs_hss_compress_lru_d(int64_t n, const double* B, int64_t ldb, const double* C, int64_t ldc, const double* M, int64_t ldm, const double* Z, int64_t ldz,
+                          int64_t r1, int64_t r2, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
+int hs_hss_compress_lru_z(int64_t n, const double* B, int64_t ldb, const double* C, int64_t ldc, const double* M, int64_t ldm, const double* Z, int64_t ldz,
+                          int64_t r1, int64_t r2, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
+
 /* later products / eliminations / solves run on `stream` (hipStream_t; NULL = the default stream); every call still returns only after its
  * work on that stream has completed */
 int hs_hss_set_stream(hs_hss* H, void* stream);

@@ -195,3 +195,29 @@ def test_permuted_matrix(hs):
     assert np.linalg.norm(H.ldiv(b) - np.linalg.solve(A, b)) / np.linalg.norm(b) < 1e-7
     Hbad = hs.hss.compress(A, leafsize=50, atol=1e-8, rtol=1e-8, kest=32)  # without it: ranks close to the block sizes
     assert Hbad.rank > 2 * H.rank
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_operator_with_low_rank_update(hs, complex_):
+    """C6 on the device: the Schur complement `S = Abb - Abi*R` with a low-rank R is compressed from products and entries, never
+    formed (`_sample_schur!` / `_getindex_schur`, factorization.jl:238-249).  Here B - C*M*Z with a smooth update of rank 24."""
+    n, r1, r2 = 900, 24, 20
+    rng = np.random.default_rng(11)
+    B = kernel_matrix(n, complex_)
+    x = np.linspace(0.0, 1.0, n)
+    Cm = np.stack([np.cos(j * x) for j in range(r1)], axis=1) * 2.0
+    Z = np.stack([np.sin((j + 1) * x) for j in range(r2)], axis=0)
+    M = rng.standard_normal((r1, r2)) + (1j * rng.standard_normal((r1, r2)) if complex_ else 0)
+    S = B - Cm @ M @ Z
+    tol = 1e-7
+    q = None if not complex_ else np.arange(n)[::-1].copy()  # also through a permutation (reversal keeps the blocks smooth)
+    H = hs.hss.compress_lowrank_update(B, Cm, M, Z, leafsize=64, atol=tol, rtol=tol, kest=32, perm=q)
+    assert np.linalg.norm(H.full() - S) / np.linalg.norm(S) < 200 * tol
+    H0 = hs.hss.compress(S, leafsize=64, atol=tol, rtol=tol, kest=32, perm=q)  # the formed matrix: same ranks up to the draw
+    assert abs(H.rank - H0.rank) <= 8, (H.rank, H0.rank)
+    b = rng.standard_normal(n)
+    assert np.linalg.norm(S @ H.ldiv(b) - b) / np.linalg.norm(b) < 1e4 * tol
+    Ho = to_oracle(H)
+    assert np.linalg.norm(HS.hss_full(Ho)[np.ix_(np.argsort(q), np.argsort(q))] - S if q is not None else HS.hss_full(Ho) - S) / np.linalg.norm(S) < 200 * tol
+    with pytest.raises(hs.DimensionMismatch):
+        hs.hss.compress_lowrank_update(B, Cm, M[:, :3], Z)
