@@ -132,6 +132,32 @@ __global__ __launch_bounds__(64) void tsolve_block_kernel(const TsJob<T>* __rest
   }
 }
 
+// rows of a leaf's basis U = P^T [I; T] at given local positions, as E (cnt x r; trans = 0) or as E^T (r x cnt; trans = 1):
+// ip[a] = index of position a in the node's order p (skeleton positions first): < r -> unit row, else row ip - r of T
+template <class T>
+struct BasisJob {
+  const T* Tm;
+  int ldt, r, cnt;
+  const int* ip;
+  T* out;
+  int ldo, trans;
+};
+template <class T>
+__global__ __launch_bounds__(64) void basis_rows_kernel(const BasisJob<T>* __restrict__ jobs) {
+  const BasisJob<T> j = jobs[blockIdx.z];
+  const int a = blockIdx.x * 64 + threadIdx.x;
+  if (a >= j.cnt) return;
+  const int c0 = blockIdx.y * 16, c1 = min(c0 + 16, j.r);
+  const int q = j.ip[a];
+  for (int c = c0; c < c1; ++c) {
+    const T v = q < j.r ? (q == c ? Scal<T>::one() : Scal<T>::zero()) : j.Tm[(size_t)(q - j.r) + (size_t)c * j.ldt];
+    if (j.trans)
+      j.out[(size_t)c + (size_t)a * j.ldo] = v;
+    else
+      j.out[(size_t)a + (size_t)c * j.ldo] = v;
+  }
+}
+
 struct IdxJob {
   const int* p;     // local positions
   const int* base;  // global index of every local position (null: lo + position)
@@ -227,6 +253,8 @@ struct HNode {
   bool has_front = false;
   NodeDesc<T> fd;
   int off_in_parent = 0;  // row offset of this node's skeleton inside the parent's local vectors
+  std::vector<int> hinvp;  // host: inverse of p (entry access, filled on first use)
+  T* NTm = nullptr;        // -T (entry access)
 };
 
 template <class T>
@@ -240,6 +268,7 @@ struct HssT {
   hipStream_t s = nullptr;
   bool own_stream = false;
   int* perm = nullptr;  // device, n entries (0-based) or null: H ~= A[perm, perm]
+  std::vector<int> hinvperm;  // host: position of every caller index in the tree's order (empty: identity)
   Pool permpool;
   bool factored = false;
   NodeDesc<T> rootfd;  // LU of the last block
@@ -825,6 +854,194 @@ void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// entries: out = H[I, J] for index lists (the `getindex` an operator assembled from HSS blocks is asked for,
+// src/factorization.jl:129-137,246-249).  O((|I| + |J|) * r) per tree level: the basis rows of the requested
+// indices are carried up the tree -- as rows E (I side) and as columns F = E^T (J side) -- and every inner node
+// contributes E_l * B12 * F_r and E_r * B21 * F_l to the block of its two index ranges; leaves contribute D[I, J].
+// ------------------------------------------------------------------------------------------------
+template <class T>
+void hss_getindex(HssT<T>& H, const int64_t* I, int ni, const int64_t* J, int nj, T* out, int ldo) {
+  hipStream_t s = H.s;
+  auto& nd = H.nd;
+  const int N = (int)nd.size();
+  Pool tmp(&H.cache);
+  if (ni <= 0 || nj <= 0) return;
+  // positions in the tree's order, sorted (the subsets of a node are contiguous then)
+  auto prep = [&](const int64_t* X, int cnt, std::vector<int>& pos, std::vector<int>& ord) {
+    pos.resize(cnt);
+    ord.resize(cnt);
+    for (int a = 0; a < cnt; ++a) {
+      if (X[a] < 0 || X[a] >= H.n) {
+        hs_set_error(HS_ERR_ARGUMENT, a, "BoundsError: index %lld outside 0:%d", (long long)X[a], H.n - 1);
+        throw (int)HS_ERR_ARGUMENT;
+      }
+      pos[a] = H.hinvperm.empty() ? (int)X[a] : H.hinvperm[(size_t)X[a]];
+      ord[a] = a;
+    }
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return pos[a] < pos[b]; });
+  };
+  std::vector<int> pI, oI, pJ, oJ;
+  prep(I, ni, pI, oI);
+  prep(J, nj, pJ, oJ);
+  std::vector<int> sI(ni), sJ(nj);  // sorted positions
+  for (int a = 0; a < ni; ++a) sI[a] = pI[oI[a]];
+  for (int a = 0; a < nj; ++a) sJ[a] = pJ[oJ[a]];
+  auto range = [](const std::vector<int>& v, int lo, int hi, int& b, int& e) {
+    b = (int)(std::lower_bound(v.begin(), v.end(), lo) - v.begin());
+    e = (int)(std::lower_bound(v.begin(), v.end(), hi) - v.begin());
+  };
+  const int ldS = ev(ni);
+  T* outS = tmp.get<T>((size_t)ldS * nj);  // result in sorted order
+  HSS_HIP(hipMemsetAsync(outS, 0, sizeof(T) * (size_t)ldS * nj, s));
+  std::vector<int> bI(N), eI(N), bJ(N), eJ(N);
+  for (int i = 0; i < N; ++i) {
+    range(sI, nd[i].lo, nd[i].hi, bI[i], eI[i]);
+    range(sJ, nd[i].lo, nd[i].hi, bJ[i], eJ[i]);
+  }
+  std::vector<SubJob<T>> subs;
+  std::vector<RowJob<T>> rows;
+  std::vector<GemmProb<T>> gemms, g2;
+  std::vector<BasisJob<T>> bjobs;
+  std::vector<T*> E(N, nullptr), F(N, nullptr);  // E: cntI x r (ld ev(cntI)); F: r x cntJ (ld ev(r))
+  int maxcnt = 0, maxr = 0;
+  // leaves: diagonal blocks and basis rows
+  for (int i = 0; i < N; ++i) {
+    HNode<T>& x = nd[i];
+    if (x.left >= 0) continue;
+    const int cI = eI[i] - bI[i], cJ = eJ[i] - bJ[i];
+    if (cI == 0 && cJ == 0) continue;
+    std::vector<int> li(cI), lj(cJ);
+    for (int a = 0; a < cI; ++a) li[a] = sI[bI[i] + a] - x.lo;
+    for (int a = 0; a < cJ; ++a) lj[a] = sJ[bJ[i] + a] - x.lo;
+    if (cI > 0 && cJ > 0) {
+      int* dli = upload(tmp, li);
+      int* dlj = upload(tmp, lj);
+      subs.push_back(SubJob<T>{x.D, x.ldd, dli, dlj, 0, 0, cI, cJ, outS + bI[i] + (size_t)ldS * bJ[i], ldS, 0});
+    }
+    if (i == 0) continue;
+    if (x.hinvp.empty()) {
+      std::vector<int> hp(x.m);
+      HSS_HIP(hipMemcpy(hp.data(), x.p, sizeof(int) * x.m, hipMemcpyDeviceToHost));
+      x.hinvp.assign(x.m, 0);
+      for (int a = 0; a < x.m; ++a) x.hinvp[hp[a]] = a;
+    }
+    for (int side = 0; side < 2; ++side) {
+      const std::vector<int>& l = side == 0 ? li : lj;
+      const int cnt = (int)l.size();
+      if (cnt == 0) continue;
+      std::vector<int> ip(cnt);
+      for (int a = 0; a < cnt; ++a) ip[a] = x.hinvp[l[a]];
+      int* dip = upload(tmp, ip);
+      T* o = side == 0 ? (E[i] = tmp.get<T>((size_t)ev(cnt) * x.r)) : (F[i] = tmp.get<T>((size_t)ev(x.r) * cnt));
+      bjobs.push_back(BasisJob<T>{x.Tm, x.ldt, x.r, cnt, dip, o, side == 0 ? ev(cnt) : ev(x.r), side});
+      maxcnt = std::max(maxcnt, cnt);
+      maxr = std::max(maxr, x.r);
+    }
+  }
+  run_subs(tmp, subs, s);
+  if (!bjobs.empty()) {
+    BasisJob<T>* dj = upload(tmp, bjobs);
+    hipLaunchKernelGGL(basis_rows_kernel<T>, dim3((maxcnt + 63) / 64, (maxr + 15) / 16, (unsigned)bjobs.size()), dim3(64), 0, s, (const BasisJob<T>*)dj);
+  }
+  // inner nodes, deepest level first: couplings of the two children, then the node's own basis rows for its parent
+  for (int lv = H.nlev - 2; lv >= 0; --lv) {
+    std::vector<GemmProb<T>> ga, gb;
+    std::vector<RowJob<T>> rj;
+    for (int i : H.lev[lv]) {
+      HNode<T>& x = nd[i];
+      if (x.left < 0) continue;
+      const int l = x.left, r = x.right, rl = nd[l].r, rr = nd[r].r;
+      const int cIl = eI[l] - bI[l], cIr = eI[r] - bI[r], cJl = eJ[l] - bJ[l], cJr = eJ[r] - bJ[r];
+      // out[I_l, J_r] = E_l * B12 * F_r,  out[I_r, J_l] = E_r * B21 * F_l
+      if (cIl > 0 && cJr > 0 && rl > 0 && rr > 0) {
+        T* t = tmp.get<T>((size_t)ev(cIl) * rr);
+        HSS_HIP(hipMemsetAsync(t, 0, sizeof(T) * (size_t)ev(cIl) * rr, s));
+        ga.push_back(GemmProb<T>{E[l], x.B12, t, cIl, rr, rl, ev(cIl), x.ld12, ev(cIl)});
+        gb.push_back(GemmProb<T>{t, F[r], outS + bI[l] + (size_t)ldS * bJ[r], cIl, cJr, rr, ev(cIl), ev(rr), ldS});
+      }
+      if (cIr > 0 && cJl > 0 && rl > 0 && rr > 0) {
+        T* t = tmp.get<T>((size_t)ev(cIr) * rl);
+        HSS_HIP(hipMemsetAsync(t, 0, sizeof(T) * (size_t)ev(cIr) * rl, s));
+        ga.push_back(GemmProb<T>{E[r], x.B21, t, cIr, rl, rr, ev(cIr), x.ld21, ev(cIr)});
+        gb.push_back(GemmProb<T>{t, F[l], outS + bI[r] + (size_t)ldS * bJ[l], cIr, cJl, rl, ev(cIr), ev(rl), ldS});
+      }
+      if (i == 0) continue;
+      // the node's own rows: W = [E_l 0; 0 E_r] -> E = W[:, p_S] + W[:, p_R] * T;   Wt = [F_l 0; 0 F_r] -> F = Wt[p_S, :] + T^T * Wt[p_R, :]
+      const int m = x.m, rk = x.r, nR = m - rk;
+      if (!x.NTm && nR > 0) {
+        x.NTm = H.keep.template get<T>((size_t)x.ldt * rk);
+        rows.push_back(RowJob<T>{x.Tm, x.ldt, x.NTm, x.ldt, nullptr, nR, rk, ROW_GATHER_NEG});
+      }
+      const int cI = cIl + cIr, cJ = cJl + cJr;
+      if (cI > 0) {
+        const int ldw = ev(cI);
+        T* W = tmp.get<T>((size_t)ldw * m);
+        HSS_HIP(hipMemsetAsync(W, 0, sizeof(T) * (size_t)ldw * m, s));
+        if (cIl > 0) subs.push_back(SubJob<T>{E[l], ev(cIl), nullptr, nullptr, 0, 0, cIl, rl, W, ldw, 0});
+        if (cIr > 0) subs.push_back(SubJob<T>{E[r], ev(cIr), nullptr, nullptr, 0, 0, cIr, rr, W + cIl + (size_t)ldw * rl, ldw, 0});
+        E[i] = tmp.get<T>((size_t)ldw * rk);
+        T* Wr = nR > 0 ? tmp.get<T>((size_t)ldw * nR) : nullptr;
+        // column gathers by p: queued behind the block copies (second batch below)
+        g2.push_back(GemmProb<T>{W, nullptr, E[i], cI, rk, 0, ldw, 0, ldw});  // placeholder carrying W / E (see below)
+        g2.back().B = (const T*)Wr;
+        g2.back().K = nR;
+      }
+      if (cJ > 0) {
+        const int ldw = ev(m);
+        T* Wt = tmp.get<T>((size_t)ldw * cJ);
+        HSS_HIP(hipMemsetAsync(Wt, 0, sizeof(T) * (size_t)ldw * cJ, s));
+        if (cJl > 0) subs.push_back(SubJob<T>{F[l], ev(rl), nullptr, nullptr, 0, 0, rl, cJl, Wt, ldw, 0});
+        if (cJr > 0) subs.push_back(SubJob<T>{F[r], ev(rr), nullptr, nullptr, 0, 0, rr, cJr, Wt + rl + (size_t)ldw * cJl, ldw, 0});
+        F[i] = tmp.get<T>((size_t)ev(rk) * cJ);
+        rj.push_back(RowJob<T>{Wt, ldw, F[i], ev(rk), x.p, rk, cJ, ROW_GATHER});
+        if (nR > 0) {
+          T* t = tmp.get<T>((size_t)ev(nR) * cJ);
+          rj.push_back(RowJob<T>{Wt, ldw, t, ev(nR), x.p + rk, nR, cJ, ROW_GATHER_NEG});
+          gemms.push_back(GemmProb<T>{x.Tt, t, F[i], rk, cJ, nR, x.ldtt, ev(nR), ev(rk)});  // F += T^T * Wt[p_R, :]
+        }
+      }
+    }
+    run_rows(tmp, rows, s);   // -T copies
+    run_gemms(tmp, ga, 0, s);
+    run_gemms(tmp, gb, 0, s);
+    run_subs(tmp, subs, s);   // W, Wt blocks
+    // E side: column gathers W[:, p_S] -> E, W[:, p_R] -> Wr, then E -= Wr * (-T)
+    std::vector<SubJob<T>> cg;
+    std::vector<GemmProb<T>> ge;
+    {
+      size_t gi = 0;
+      for (int i : H.lev[lv]) {
+        HNode<T>& x = nd[i];
+        if (x.left < 0 || i == 0) continue;
+        const int cI = (eI[x.left] - bI[x.left]) + (eI[x.right] - bI[x.right]);
+        if (cI <= 0) continue;
+        const GemmProb<T>& ph = g2[gi++];
+        const int ldw = ev(cI), rk = x.r, nR = x.m - rk;
+        cg.push_back(SubJob<T>{ph.A, ldw, nullptr, x.p, 0, 0, cI, rk, ph.C, ldw, 0});
+        if (nR > 0) {
+          cg.push_back(SubJob<T>{ph.A, ldw, nullptr, x.p + rk, 0, 0, cI, nR, (T*)ph.B, ldw, 0});
+          ge.push_back(GemmProb<T>{ph.B, x.NTm, ph.C, cI, rk, nR, ldw, x.ldt, ldw});
+        }
+      }
+      g2.clear();
+    }
+    run_subs(tmp, cg, s);
+    run_gemms(tmp, ge, 1, s);
+    run_rows(tmp, rj, s);
+    run_gemms(tmp, gemms, 1, s);
+  }
+  // back to the caller's order
+  std::vector<int> rI(ni), rJ(nj);
+  for (int a = 0; a < ni; ++a) rI[oI[a]] = a;
+  for (int a = 0; a < nj; ++a) rJ[oJ[a]] = a;
+  int* drI = upload(tmp, rI);
+  int* drJ = upload(tmp, rJ);
+  subs.push_back(SubJob<T>{outS, ldS, drI, drJ, 0, 0, ni, nj, out, ldo, 0});
+  run_subs(tmp, subs, s);
+  HSS_HIP(hipStreamSynchronize(s));
+}
+
+// ------------------------------------------------------------------------------------------------
 // elimination
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -1129,6 +1346,8 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
       seen[(size_t)perm[i]] = 1;
       hp[(size_t)i] = (int)perm[i];
     }
+    H->hinvperm.assign((size_t)n, 0);
+    for (int64_t i = 0; i < n; ++i) H->hinvperm[(size_t)hp[(size_t)i]] = (int)i;
     H->perm = H->permpool.template get<int>((size_t)n);
     HSS_HIP(hipMemcpy(H->perm, hp.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
   }
@@ -1348,6 +1567,31 @@ extern "C" int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, in
                                                  [&](const cplx* a, int la, cplx* b, int lb) { hss_mul<cplx>(*HZ(H), a, la, b, lb, (int)nrhs); });
       else with_device_block<double>(HD(H)->n, X, ldx, Y, ldy, (int)nrhs, where,
                                      [&](const double* a, int la, double* b, int lb) { hss_mul<double>(*HD(H), a, la, b, lb, (int)nrhs); }));
+}
+
+extern "C" int hs_hss_getindex(hs_hss* H, const int64_t* I, int64_t ni, const int64_t* J, int64_t nj, double* out, int64_t ldo, int where) {
+  if (!H || !out || ni < 0 || nj < 0 || (ni > 0 && !I) || (nj > 0 && !J) || ldo < ni) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_getindex needs index lists and an ni x nj result");
+    return HS_ERR_ARGUMENT;
+  }
+  if (ni == 0 || nj == 0) return HS_OK;
+  HSS_GUARD(
+      if (where != 0) {
+        if (H->is_complex) hss_getindex<cplx>(*HZ(H), I, (int)ni, J, (int)nj, (cplx*)out, (int)ldo);
+        else hss_getindex<double>(*HD(H), I, (int)ni, J, (int)nj, out, (int)ldo);
+      } else {
+        Pool st;
+        const int ld = ev((int)ni);
+        if (H->is_complex) {
+          cplx* d = st.get<cplx>((size_t)ld * nj);
+          hss_getindex<cplx>(*HZ(H), I, (int)ni, J, (int)nj, d, ld);
+          HSS_HIP(hipMemcpy2D(out, sizeof(cplx) * ldo, d, sizeof(cplx) * ld, sizeof(cplx) * ni, nj, hipMemcpyDeviceToHost));
+        } else {
+          double* d = st.get<double>((size_t)ld * nj);
+          hss_getindex<double>(*HD(H), I, (int)ni, J, (int)nj, d, ld);
+          HSS_HIP(hipMemcpy2D(out, sizeof(double) * ldo, d, sizeof(double) * ld, sizeof(double) * ni, nj, hipMemcpyDeviceToHost));
+        }
+      });
 }
 
 extern "C" int hs_hss_factor(hs_hss* H) {

@@ -92,6 +92,16 @@ class HssMatrix:
         d["B21"] = B21.T.copy() if B21 is not None else None
         return d
 
+    def getindex(self, I, J):
+        """``H[I, J]`` for 0-based index lists (entry access without expanding the matrix)."""
+        I = np.ascontiguousarray(I, dtype=np.int64).reshape(-1)
+        J = np.ascontiguousarray(J, dtype=np.int64).reshape(-1)
+        out = np.zeros((len(J), len(I)), dtype=self.dtype)  # column-major ni x nj
+        if out.size:
+            _lib.check(self.L.hs_hss_getindex(self._h, I.ctypes.data_as(_lib.p_i64), len(I), J.ctypes.data_as(_lib.p_i64), len(J),
+                                              out.ctypes.data_as(C.c_void_p), len(I), 0))
+        return out.T.copy()
+
     def _block(self, X):
         X = np.asarray(X)
         one = X.ndim == 1

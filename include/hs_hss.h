@@ -79,6 +79,11 @@ int hs_hss_node_info(const hs_hss* H, int64_t node, int64_t out[8]);
  * p[m] (0-based local positions, skeleton first), T ((m-r) x r), D (m x m, leaves), B12 (r_l x r_r), B21 (r_r x r_l) */
 int hs_hss_node_data(const hs_hss* H, int64_t node, int64_t* p, double* T, double* D, double* B12, double* B21);
 
+/* out (ni x nj, leading dimension ldo) = H[I, J] for 0-based index lists on the HOST (in the caller's index order): the entry access an
+ * operator assembled from HSS blocks is asked for (`S.A11[...]` inside `_getindex_schur`, src/factorization.jl:246-249; the blocks
+ * `randcompress_adaptive` reads).  O((ni + nj) * rank) per tree level; `where` says where `out` lives. */
+int hs_hss_getindex(hs_hss* H, const int64_t* I, int64_t ni, const int64_t* J, int64_t nj, double* out, int64_t ldo, int where);
+
 /* Y = H * X for n x nrhs blocks */
 int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where);
 /* ULV-type elimination of the HSS matrix (once), then B <- H^-1 B in place */

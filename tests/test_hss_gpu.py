@@ -221,3 +221,31 @@ def test_operator_with_low_rank_update(hs, complex_):
     assert np.linalg.norm(HS.hss_full(Ho)[np.ix_(np.argsort(q), np.argsort(q))] - S if q is not None else HS.hss_full(Ho) - S) / np.linalg.norm(S) < 200 * tol
     with pytest.raises(hs.DimensionMismatch):
         hs.hss.compress_lowrank_update(B, Cm, M[:, :3], Z)
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_entry_access(hs, complex_):
+    """`H[I, J]` on the device against the oracle's recursive getindex on the same generators, and against the matrix."""
+    n = 900
+    A = kernel_matrix(n, complex_, seed=4)
+    H = hs.hss.compress(A, hs.hss.bisection_cluster((333, n), leafsize=48), atol=1e-9, rtol=1e-9, kest=32)
+    Ho = to_oracle(H)
+    rng = np.random.default_rng(9)
+    for ni, nj in ((1, 1), (37, 120), (300, 5), (n, 40)):
+        I = rng.integers(0, n, ni) if ni < n else rng.permutation(n)
+        J = rng.integers(0, n, nj)
+        G = H.getindex(I, J)
+        Go = HS.hss_getindex(Ho, I, J)
+        assert G.shape == (ni, nj)
+        assert np.abs(G - Go).max() <= 1e-12 * np.abs(A).max() * 50, (ni, nj, np.abs(G - Go).max())
+        assert np.abs(G - A[np.ix_(I, J)]).max() <= 1e-6 * np.abs(A).max()
+    # through a permutation: indices are the caller's
+    q = rng.permutation(n)
+    inv = np.argsort(q)
+    Ap = A[np.ix_(inv, inv)]
+    Hp = hs.hss.compress(Ap, leafsize=48, atol=1e-9, rtol=1e-9, kest=32, perm=q)
+    I, J = rng.integers(0, n, 64), rng.integers(0, n, 77)
+    assert np.abs(Hp.getindex(I, J) - Ap[np.ix_(I, J)]).max() <= 1e-6 * np.abs(A).max()
+    with pytest.raises(ValueError):
+        H.getindex([n], [0])
+    assert H.getindex([], [1, 2]).shape == (0, 2)
