@@ -255,6 +255,7 @@ struct HNode {
   int off_in_parent = 0;  // row offset of this node's skeleton inside the parent's local vectors
   std::vector<int> hinvp;  // host: inverse of p (entry access, filled on first use)
   T* NTm = nullptr;        // -T (entry access)
+  T *DTt = nullptr, *B12t = nullptr, *B21t = nullptr;  // D^T, B12^T (rr x rl), B21^T (rl x rr): transposed product, made on first use
 };
 
 template <class T>
@@ -755,12 +756,12 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
 // Y = H * X
 // ------------------------------------------------------------------------------------------------
 template <class T>
-void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q);
-// Y = H * X in the caller's index order: the tree works on the permuted vectors
+void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q, bool trans);
+// Y = H * X (trans: H^T * X, plain transpose) in the caller's index order: the tree works on the permuted vectors
 template <class T>
-void hss_mul(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q) {
+void hss_mul(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q, bool trans = false) {
   if (!H.perm) {
-    hss_mul_p(H, X, ldx, Y, ldy, q);
+    hss_mul_p(H, X, ldx, Y, ldy, q, trans);
     return;
   }
   Pool tmp(&H.cache);
@@ -769,22 +770,40 @@ void hss_mul(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q) {
   T* Yp = tmp.get<T>((size_t)ld * q);
   std::vector<RowJob<T>> rows{RowJob<T>{X, ldx, Xp, ld, H.perm, H.n, q, ROW_GATHER}};
   run_rows(tmp, rows, H.s);
-  hss_mul_p(H, Xp, ld, Yp, ld, q);
+  hss_mul_p(H, Xp, ld, Yp, ld, q, trans);
   rows.push_back(RowJob<T>{Yp, ld, Y, ldy, H.perm, H.n, q, ROW_SCATTER});
   run_rows(tmp, rows, H.s);
   HSS_HIP(hipStreamSynchronize(H.s));
 }
 template <class T>
-void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q) {
+void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q, bool trans) {
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
   Pool tmp(&H.cache);
   std::vector<RowJob<T>> rows;
   std::vector<GemmProb<T>> gemms;
+  if (trans) {  // H^T has the same bases (U = V) and the generators D^T, B12 <- B21^T, B21 <- B12^T: transposed copies on first use
+    std::vector<SubJob<T>> tj;
+    for (auto& x : nd) {
+      if (x.left < 0) {
+        if (!x.DTt && x.D) {
+          x.DTt = H.keep.template get<T>((size_t)x.ldd * x.m);
+          tj.push_back(SubJob<T>{x.D, x.ldd, nullptr, nullptr, 0, 0, x.m, x.m, x.DTt, x.ldd, 1});
+        }
+      } else if (!x.B12t) {
+        const int rl = nd[x.left].r, rr = nd[x.right].r;
+        x.B12t = H.keep.template get<T>((size_t)ev(rr) * rl);
+        x.B21t = H.keep.template get<T>((size_t)ev(rl) * rr);
+        tj.push_back(SubJob<T>{x.B12, x.ld12, nullptr, nullptr, 0, 0, rl, rr, x.B12t, ev(rr), 1});
+        tj.push_back(SubJob<T>{x.B21, x.ld21, nullptr, nullptr, 0, 0, rr, rl, x.B21t, ev(rl), 1});
+      }
+    }
+    run_subs(tmp, tj, s);
+  }
   if (nd[0].left < 0) {
     HSS_HIP(hipMemset2DAsync(Y, sizeof(T) * ldy, 0, sizeof(T) * H.n, q, s));
-    gemms.push_back(GemmProb<T>{nd[0].D, X, Y, H.n, q, H.n, nd[0].ldd, ldx, ldy});
+    gemms.push_back(GemmProb<T>{trans ? nd[0].DTt : nd[0].D, X, Y, H.n, q, H.n, nd[0].ldd, ldx, ldy});
     run_gemms(tmp, gemms, 0, s);
     HSS_HIP(hipStreamSynchronize(s));
     return;
@@ -827,13 +846,18 @@ void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q) {
         blk = Y + x.lo;
         ldb = ldy;
         HSS_HIP(hipMemset2DAsync(blk, sizeof(T) * ldy, 0, sizeof(T) * x.m, q, s));
-        gemms.push_back(GemmProb<T>{x.D, X + x.lo, blk, x.m, q, x.m, x.ldd, ldx, ldy});
+        gemms.push_back(GemmProb<T>{trans ? x.DTt : x.D, X + x.lo, blk, x.m, q, x.m, x.ldd, ldx, ldy});
       } else {
         blk = G[i];
         ldb = ldx_[i];
         const int rl = nd[x.left].r, rr = nd[x.right].r;
-        gemms.push_back(GemmProb<T>{x.B12, XT[i] + rl, blk, rl, q, rr, x.ld12, ldx_[i], ldb});
-        gemms.push_back(GemmProb<T>{x.B21, XT[i], blk + rl, rr, q, rl, x.ld21, ldx_[i], ldb});
+        if (!trans) {
+          gemms.push_back(GemmProb<T>{x.B12, XT[i] + rl, blk, rl, q, rr, x.ld12, ldx_[i], ldb});
+          gemms.push_back(GemmProb<T>{x.B21, XT[i], blk + rl, rr, q, rl, x.ld21, ldx_[i], ldb});
+        } else {
+          gemms.push_back(GemmProb<T>{x.B21t, XT[i] + rl, blk, rl, q, rr, ev(rl), ldx_[i], ldb});
+          gemms.push_back(GemmProb<T>{x.B12t, XT[i], blk + rl, rr, q, rl, ev(rr), ldx_[i], ldb});
+        }
       }
       if (i != 0) {  // the contribution that arrives from above: U_i * g
         const int par = x.parent, r = x.r, nR = x.m - r;
@@ -1556,7 +1580,7 @@ static void with_device_block(int n, const T* Bin, int64_t ldin, T* Bout, int64_
   HSS_HIP(hipMemcpy2D(Bout, sizeof(T) * ldout, dO, sizeof(T) * ld, sizeof(T) * n, q, hipMemcpyDeviceToHost));
 }
 
-extern "C" int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where) {
+static int hss_mul_abi(bool trans, hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where) {
   if (!H || !X || !Y || nrhs < 0 || X == Y) {
     hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_mul needs distinct X and Y");
     return HS_ERR_ARGUMENT;
@@ -1564,9 +1588,78 @@ extern "C" int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, in
   if (nrhs == 0) return HS_OK;
   HSS_GUARD(
       if (H->is_complex) with_device_block<cplx>(HZ(H)->n, (const cplx*)X, ldx, (cplx*)Y, ldy, (int)nrhs, where,
-                                                 [&](const cplx* a, int la, cplx* b, int lb) { hss_mul<cplx>(*HZ(H), a, la, b, lb, (int)nrhs); });
+                                                 [&](const cplx* a, int la, cplx* b, int lb) { hss_mul<cplx>(*HZ(H), a, la, b, lb, (int)nrhs, trans); });
       else with_device_block<double>(HD(H)->n, X, ldx, Y, ldy, (int)nrhs, where,
-                                     [&](const double* a, int la, double* b, int lb) { hss_mul<double>(*HD(H), a, la, b, lb, (int)nrhs); }));
+                                     [&](const double* a, int la, double* b, int lb) { hss_mul<double>(*HD(H), a, la, b, lb, (int)nrhs, trans); }));
+}
+
+extern "C" int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where) {
+  return hss_mul_abi(false, H, X, ldx, Y, ldy, nrhs, where);
+}
+extern "C" int hs_hss_mul_t(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where) {
+  return hss_mul_abi(true, H, X, ldx, Y, ldy, nrhs, where);
+}
+
+// `H.A11` (which = 0) / `H.A22` (which = 1): the diagonal block of the top-level split as an HSS matrix of its own that SHARES the
+// generators of H (H must outlive it).  Its index space is the block's own: 0 .. size-1 in the order of the cluster tree.
+template <class T>
+static HssT<T>* child_impl(HssT<T>* P, int which) {
+  if (P->nd[0].left < 0) {
+    hs_set_error(HS_ERR_HSS_LEAF, 0, "One of the Schur complements turned into a leaf. Aborting.");  // factorization.jl:164
+    throw (int)HS_ERR_HSS_LEAF;
+  }
+  const int top = which == 0 ? P->nd[0].left : P->nd[0].right;
+  const int off = P->nd[top].lo;
+  std::vector<int> ids, cur{top};
+  while (!cur.empty()) {  // breadth-first renumbering of the subtree
+    std::vector<int> nxt;
+    for (int i : cur) {
+      ids.push_back(i);
+      if (P->nd[i].left >= 0) {
+        nxt.push_back(P->nd[i].left);
+        nxt.push_back(P->nd[i].right);
+      }
+    }
+    cur.swap(nxt);
+  }
+  std::vector<int> nw(P->nd.size(), -1);
+  for (size_t k = 0; k < ids.size(); ++k) nw[ids[k]] = (int)k;
+  std::unique_ptr<HssT<T>> C(new HssT<T>());
+  C->n = P->nd[top].hi - off;
+  C->k = P->k;
+  C->opt = P->opt;
+  C->s = P->s;
+  C->own_stream = false;
+  for (int old : ids) {
+    HNode<T> y = P->nd[old];  // shares every device pointer
+    y.lo -= off;
+    y.hi -= off;
+    y.level -= 1;
+    y.parent = old == top ? -1 : nw[y.parent];
+    if (y.left >= 0) {
+      y.left = nw[y.left];
+      y.right = nw[y.right];
+    }
+    y.has_front = false;
+    memset(&y.fd, 0, sizeof y.fd);
+    if (old == top) {  // a root keeps no basis
+      y.p = nullptr; y.sk = nullptr; y.Tm = nullptr; y.Tt = nullptr; y.NTm = nullptr;
+      y.m = y.left >= 0 ? P->nd[P->nd[old].left].r + P->nd[P->nd[old].right].r : y.hi - y.lo;
+      y.r = 0;
+      y.hinvp.clear();
+    }
+    C->nd.push_back(y);
+  }
+  C->nlev = 0;
+  for (auto& x : C->nd) C->nlev = std::max(C->nlev, x.level + 1);
+  C->lev.assign(C->nlev, {});
+  for (int i = 0; i < (int)C->nd.size(); ++i) C->lev[C->nd[i].level].push_back(i);
+  return C.release();
+}
+extern "C" int hs_hss_child(hs_hss* H, int which, hs_hss** out) {
+  if (!H || !out || (which != 0 && which != 1)) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  HSS_GUARD(*out = H->is_complex ? new hs_hss{1, child_impl<cplx>(HZ(H), which)} : new hs_hss{0, child_impl<double>(HD(H), which)});
 }
 
 extern "C" int hs_hss_getindex(hs_hss* H, const int64_t* I, int64_t ni, const int64_t* J, int64_t nj, double* out, int64_t ldo, int where) {

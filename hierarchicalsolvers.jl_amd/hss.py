@@ -29,8 +29,9 @@ def bisection_cluster(n, leafsize=64):
 class HssMatrix:
     """Device-resident HSS form of a dense square matrix."""
 
-    def __init__(self, handle, is_complex):
+    def __init__(self, handle, is_complex, parent=None):
         self._h, self.is_complex = handle, bool(is_complex)
+        self._parent = parent  # a block view shares its parent's generators: keep the parent alive
         self.dtype = np.complex128 if is_complex else np.float64
         self.L = _lib.lib()
 
@@ -116,6 +117,20 @@ class HssMatrix:
         return Y[:, 0] if one else Y
 
     __matmul__ = matmul
+
+    def rmatmul_t(self, X):
+        """``H^T @ X`` (plain transpose)."""
+        X2, one = self._block(X)
+        Y = np.zeros_like(X2, order="F")
+        n, q = X2.shape
+        _lib.check(self.L.hs_hss_mul_t(self._h, X2.ctypes.data_as(C.c_void_p), n, Y.ctypes.data_as(C.c_void_p), n, q, 0))
+        return Y[:, 0] if one else Y
+
+    def block(self, which):
+        """``H.A11`` (0) or ``H.A22`` (1): the diagonal block of the top-level split as an HSS matrix sharing this one's generators."""
+        h = C.c_void_p()
+        _lib.check(self.L.hs_hss_child(self._h, int(which), C.byref(h)))
+        return HssMatrix(h, self.is_complex, parent=self)
 
     def factor(self):
         _lib.check(self.L.hs_hss_factor(self._h))

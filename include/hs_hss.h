@@ -86,6 +86,12 @@ int hs_hss_getindex(hs_hss* H, const int64_t* I, int64_t ni, const int64_t* J, i
 
 /* Y = H * X for n x nrhs blocks */
 int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where);
+/* Y = H^T * X (plain transpose; the samples `X^T A` of an operator that contains H) */
+int hs_hss_mul_t(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where);
+/* `H.A11` (which = 0) / `H.A22` (which = 1) of the top-level split as an HSS matrix that SHARES H's generators (H must outlive it):
+ * what `_assemble_blocks` reads from a child's Schur complement (src/factorization.jl:127-135).  Its index space is the block's own,
+ * 0 .. size-1 in cluster-tree order.  HS_ERR_HSS_LEAF when H is a single leaf (factorization.jl:164). */
+int hs_hss_child(hs_hss* H, int which, hs_hss** out);
 /* ULV-type elimination of the HSS matrix (once), then B <- H^-1 B in place */
 int hs_hss_factor(hs_hss* H);
 int hs_hss_ldiv(hs_hss* H, double* B, int64_t ldb, int64_t nrhs, int where);

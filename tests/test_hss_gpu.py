@@ -249,3 +249,30 @@ def test_entry_access(hs, complex_):
     with pytest.raises(ValueError):
         H.getindex([n], [0])
     assert H.getindex([], [1, 2]).shape == (0, 2)
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_transposed_product_and_block_views(hs, complex_):
+    """`H^T X`, and `H.A11` / `H.A22` as HSS matrices sharing H's generators (what a parent front reads from a child's S)."""
+    n, n1 = 800, 300
+    A = kernel_matrix(n, complex_, seed=6)
+    H = hs.hss.compress(A, hs.hss.bisection_cluster((n1, n), leafsize=50), atol=1e-9, rtol=1e-9, kest=32)
+    Fh = H.full()
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((n, 4)) + (1j * rng.standard_normal((n, 4)) if complex_ else 0)
+    assert np.linalg.norm(H.rmatmul_t(X) - Fh.T @ X) <= 1e-12 * np.linalg.norm(Fh) * np.linalg.norm(X)
+    assert np.linalg.norm(H @ X - Fh @ X) <= 1e-12 * np.linalg.norm(Fh) * np.linalg.norm(X)  # the plain product is untouched
+    H11, H22 = H.block(0), H.block(1)
+    assert H11.shape == (n1, n1) and H22.shape == (n - n1, n - n1)
+    assert np.allclose(H11.full(), Fh[:n1, :n1], atol=1e-12 * np.abs(Fh).max())
+    assert np.allclose(H22.full(), Fh[n1:, n1:], atol=1e-12 * np.abs(Fh).max())
+    I, J = rng.integers(0, n - n1, 50), rng.integers(0, n - n1, 60)
+    assert np.allclose(H22.getindex(I, J), Fh[n1:, n1:][np.ix_(I, J)], atol=1e-12 * np.abs(Fh).max())
+    b = X[:n1]
+    assert np.linalg.norm(H11.ldiv(b) - np.linalg.solve(Fh[:n1, :n1], b)) / np.linalg.norm(b) < 1e-9
+    assert np.linalg.norm(H11.rmatmul_t(b) - Fh[:n1, :n1].T @ b) <= 1e-12 * np.linalg.norm(Fh) * np.linalg.norm(b)
+    assert H11.rank <= H.rank and H11.block(0).shape[0] == (n1 + 1) // 2  # views nest
+    del H11, H22
+    assert np.allclose(H.full(), Fh)  # the parent is intact after its views are gone
+    with pytest.raises(RuntimeError, match="turned into a leaf"):
+        hs.hss.compress(kernel_matrix(30), leafsize=64).block(0)
