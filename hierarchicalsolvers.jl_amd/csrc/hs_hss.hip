@@ -1066,6 +1066,98 @@ void hss_getindex(HssT<T>& H, const int64_t* I, int ni, const int64_t* J, int nj
 }
 
 // ------------------------------------------------------------------------------------------------
+// expanded basis of one node: out (size(node) x r) = U_big, A(I_node, far) ~= U_big * A(sk_node, far) -- the `generators(S.A11)` /
+// `U*B12`, `V` factors a parent front builds its low-rank couplings from (src/factorization.jl:129-137).  Bottom-up over the subtree:
+// leaf U = P^T [I; T]; inner node U = blkdiag(U_left, U_right) * P^T [I; T].
+// ------------------------------------------------------------------------------------------------
+template <class T>
+void hss_basis(HssT<T>& H, int node, T* out, int ldo) {
+  hipStream_t s = H.s;
+  auto& nd = H.nd;
+  const int N = (int)nd.size();
+  if (node <= 0 || node >= N) {
+    hs_set_error(HS_ERR_ARGUMENT, node, "ArgumentError: HSS node %d has no basis (the root has none)", node);
+    throw (int)HS_ERR_ARGUMENT;
+  }
+  Pool tmp(&H.cache);
+  // the subtree, by level
+  std::vector<std::vector<int>> lv(H.nlev);
+  std::vector<int> cur{node};
+  while (!cur.empty()) {
+    std::vector<int> nxt;
+    for (int i : cur) {
+      lv[nd[i].level].push_back(i);
+      if (nd[i].left >= 0) {
+        nxt.push_back(nd[i].left);
+        nxt.push_back(nd[i].right);
+      }
+    }
+    cur.swap(nxt);
+  }
+  std::vector<T*> E(N, nullptr);
+  std::vector<int> lde(N, 0);
+  auto target = [&](int i) {  // the requested node writes straight into `out`
+    if (i == node) {
+      E[i] = out;
+      lde[i] = ldo;
+    } else {
+      lde[i] = ev(nd[i].hi - nd[i].lo);
+      E[i] = tmp.get<T>((size_t)lde[i] * nd[i].r);
+    }
+  };
+  for (int l = H.nlev - 1; l >= nd[node].level; --l) {
+    std::vector<BasisJob<T>> bj;
+    std::vector<SubJob<T>> blocks, cg;
+    std::vector<RowJob<T>> neg;
+    std::vector<GemmProb<T>> ge;
+    int maxcnt = 0, maxr = 0;
+    for (int i : lv[l]) {
+      HNode<T>& x = nd[i];
+      const int cnt = x.hi - x.lo, rk = x.r, nR = x.m - rk;
+      target(i);
+      if (x.left < 0) {
+        if (x.hinvp.empty()) {
+          std::vector<int> hp(x.m);
+          HSS_HIP(hipMemcpy(hp.data(), x.p, sizeof(int) * x.m, hipMemcpyDeviceToHost));
+          x.hinvp.assign(x.m, 0);
+          for (int a = 0; a < x.m; ++a) x.hinvp[hp[a]] = a;
+        }
+        int* dip = upload(tmp, x.hinvp);
+        bj.push_back(BasisJob<T>{x.Tm, x.ldt, rk, cnt, dip, E[i], lde[i], 0});
+        maxcnt = std::max(maxcnt, cnt);
+        maxr = std::max(maxr, rk);
+        continue;
+      }
+      const int cl = nd[x.left].hi - nd[x.left].lo, cr = cnt - cl, rl = nd[x.left].r, rr = nd[x.right].r;
+      const int ldw = ev(cnt);
+      T* W = tmp.get<T>((size_t)ldw * x.m);
+      HSS_HIP(hipMemsetAsync(W, 0, sizeof(T) * (size_t)ldw * x.m, s));
+      blocks.push_back(SubJob<T>{E[x.left], lde[x.left], nullptr, nullptr, 0, 0, cl, rl, W, ldw, 0});
+      blocks.push_back(SubJob<T>{E[x.right], lde[x.right], nullptr, nullptr, 0, 0, cr, rr, W + cl + (size_t)ldw * rl, ldw, 0});
+      cg.push_back(SubJob<T>{W, ldw, nullptr, x.p, 0, 0, cnt, rk, E[i], lde[i], 0});
+      if (nR > 0) {
+        if (!x.NTm) {
+          x.NTm = H.keep.template get<T>((size_t)x.ldt * rk);
+          neg.push_back(RowJob<T>{x.Tm, x.ldt, x.NTm, x.ldt, nullptr, nR, rk, ROW_GATHER_NEG});
+        }
+        T* Wr = tmp.get<T>((size_t)ldw * nR);
+        cg.push_back(SubJob<T>{W, ldw, nullptr, x.p + rk, 0, 0, cnt, nR, Wr, ldw, 0});
+        ge.push_back(GemmProb<T>{Wr, x.NTm, E[i], cnt, rk, nR, ldw, x.ldt, lde[i]});  // E += W[:, p_R] * T
+      }
+    }
+    if (!bj.empty()) {
+      BasisJob<T>* dj = upload(tmp, bj);
+      hipLaunchKernelGGL(basis_rows_kernel<T>, dim3((maxcnt + 63) / 64, (maxr + 15) / 16, (unsigned)bj.size()), dim3(64), 0, s, (const BasisJob<T>*)dj);
+    }
+    run_rows(tmp, neg, s);
+    run_subs(tmp, blocks, s);
+    run_subs(tmp, cg, s);
+    run_gemms(tmp, ge, 1, s);
+  }
+  HSS_HIP(hipStreamSynchronize(s));
+}
+
+// ------------------------------------------------------------------------------------------------
 // elimination
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -1683,6 +1775,39 @@ extern "C" int hs_hss_getindex(hs_hss* H, const int64_t* I, int64_t ni, const in
           double* d = st.get<double>((size_t)ld * nj);
           hss_getindex<double>(*HD(H), I, (int)ni, J, (int)nj, d, ld);
           HSS_HIP(hipMemcpy2D(out, sizeof(double) * ldo, d, sizeof(double) * ld, sizeof(double) * ni, nj, hipMemcpyDeviceToHost));
+        }
+      });
+}
+
+extern "C" int hs_hss_basis(hs_hss* H, int64_t node, double* out, int64_t ldo, int where) {
+  if (!H || !out) return HS_ERR_ARGUMENT;
+  HSS_GUARD(
+      const int64_t nn = hs_hss_num_nodes(H);
+      if (node <= 0 || node >= nn) {
+        hs_set_error(HS_ERR_ARGUMENT, node, "ArgumentError: HSS node %lld has no basis", (long long)node);
+        throw (int)HS_ERR_ARGUMENT;
+      }
+      int64_t info[8];
+      (void)hs_hss_node_info(H, node, info);
+      const int rows = (int)(info[1] - info[0]), r = (int)info[6];
+      if (ldo < rows) {
+        hs_set_error(HS_ERR_DIMENSION, 0, "DimensionMismatch: the basis has %d rows, ldo = %lld", rows, (long long)ldo);
+        throw (int)HS_ERR_DIMENSION;
+      }
+      if (where != 0) {
+        if (H->is_complex) hss_basis<cplx>(*HZ(H), (int)node, (cplx*)out, (int)ldo);
+        else hss_basis<double>(*HD(H), (int)node, out, (int)ldo);
+      } else {
+        Pool st;
+        const int ld = ev(rows);
+        if (H->is_complex) {
+          cplx* d = st.get<cplx>((size_t)ld * r);
+          hss_basis<cplx>(*HZ(H), (int)node, d, ld);
+          HSS_HIP(hipMemcpy2D(out, sizeof(cplx) * ldo, d, sizeof(cplx) * ld, sizeof(cplx) * rows, r, hipMemcpyDeviceToHost));
+        } else {
+          double* d = st.get<double>((size_t)ld * r);
+          hss_basis<double>(*HD(H), (int)node, d, ld);
+          HSS_HIP(hipMemcpy2D(out, sizeof(double) * ldo, d, sizeof(double) * ld, sizeof(double) * rows, r, hipMemcpyDeviceToHost));
         }
       });
 }

@@ -103,6 +103,20 @@ class HssMatrix:
                                               out.ctypes.data_as(C.c_void_p), len(I), 0))
         return out.T.copy()
 
+    def basis(self, node):
+        """Expanded basis ``U`` of a non-root node (``size(node) x rank``)."""
+        d = self._info(node)
+        rows, r = d["hi"] - d["lo"], d["r"]
+        out = np.zeros((r, rows), dtype=self.dtype)
+        _lib.check(self.L.hs_hss_basis(self._h, node, out.ctypes.data_as(C.c_void_p), rows, 0))
+        return out.T.copy()
+
+    def offdiag(self):
+        """The two off-diagonal blocks of the top-level split in low-rank form: ``(U1, B12, U2, B21)`` with
+        ``A12 = U1 @ B12 @ U2.T`` and ``A21 = U2 @ B21 @ U1.T`` (``generators`` / ``S.B12`` / ``S.B21``, factorization.jl:129-137)."""
+        root = self.node(0)
+        return self.basis(root["left"]), root["B12"], self.basis(root["right"]), root["B21"]
+
     def _block(self, X):
         X = np.asarray(X)
         one = X.ndim == 1

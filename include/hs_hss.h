@@ -84,6 +84,12 @@ int hs_hss_node_data(const hs_hss* H, int64_t node, int64_t* p, double* T, doubl
  * `randcompress_adaptive` reads).  O((ni + nj) * rank) per tree level; `where` says where `out` lives. */
 int hs_hss_getindex(hs_hss* H, const int64_t* I, int64_t ni, const int64_t* J, int64_t nj, double* out, int64_t ldo, int where);
 
+/* out (size(node) x r, leading dimension ldo) = the EXPANDED basis U of one non-root node, A(I_node, far) ~= U * A(sk_node, far) (and, with
+ * the plain transpose, A(far, I_node) ~= A(far, sk_node) * U^T): `generators(S.A11)` and the factors `U*B12`, `V` of a child's off-diagonal
+ * blocks that a parent front assembles its low-rank couplings from (src/factorization.jl:129-137).  Nodes 1 and 2 are the two halves of the
+ * top-level split: A12 = U_1 * B12 * U_2^T, A21 = U_2 * B21 * U_1^T with the root's B12, B21 (hs_hss_node_data). */
+int hs_hss_basis(hs_hss* H, int64_t node, double* out, int64_t ldo, int where);
+
 /* Y = H * X for n x nrhs blocks */
 int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where);
 /* Y = H^T * X (plain transpose; the samples `X^T A` of an operator that contains H) */

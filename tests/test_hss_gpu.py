@@ -276,3 +276,27 @@ def test_transposed_product_and_block_views(hs, complex_):
     assert np.allclose(H.full(), Fh)  # the parent is intact after its views are gone
     with pytest.raises(RuntimeError, match="turned into a leaf"):
         hs.hss.compress(kernel_matrix(30), leafsize=64).block(0)
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_expanded_bases_and_offdiagonal_generators(hs, complex_):
+    """`generators(S.A11)`, `S.B12`, `S.B21` (factorization.jl:129-137): A12 = U1 B12 U2^T from the expanded bases, against the oracle."""
+    n, n1 = 700, 260
+    A = kernel_matrix(n, complex_, seed=8)
+    H = hs.hss.compress(A, hs.hss.bisection_cluster((n1, n), leafsize=40), atol=1e-9, rtol=1e-9, kest=32)
+    Fh = H.full()
+    U1, B12, U2, B21 = H.offdiag()
+    assert U1.shape == (n1, B12.shape[0]) and U2.shape == (n - n1, B12.shape[1])
+    tol = 1e-12 * np.abs(Fh).max() * 50
+    assert np.abs(U1 @ B12 @ U2.T - Fh[:n1, n1:]).max() < tol
+    assert np.abs(U2 @ B21 @ U1.T - Fh[n1:, :n1]).max() < tol
+    Ho = to_oracle(H)
+    O1, _, O2, _ = HS.hss_offdiag(Ho)
+    assert np.abs(U1 - O1).max() < 1e-12 * max(1.0, np.abs(O1).max()) * 50 and np.abs(U2 - O2).max() < 1e-12 * max(1.0, np.abs(O2).max()) * 50
+    # a deeper node: its basis reproduces the block row against the rest through the node's skeleton rows (interpolation property)
+    k = 5
+    d = H._info(k)
+    Uk = H.basis(k)
+    assert Uk.shape == (d["hi"] - d["lo"], d["r"])
+    with pytest.raises(ValueError):
+        H.basis(0)
