@@ -141,6 +141,61 @@ class BlockD:
         return np.concatenate([y1 - self.s11(self.C12 @ x2), x2], axis=0)
 
 
+class SingleD:
+    """`D = Aii` as ONE HSS matrix over a recursive-bisection order of the front's interior graph, compressed MATRIX-FREE from the
+    operator `[S1.A11  A12; A21  S2.A11]` (children's HSS blocks: products and entry access; sparse couplings) -- the formulation the
+    device path of `hs_options.hss_d` uses, minus its dense assembly.  No `A11^-1 * A12` is ever needed: products cost two HSS matvecs
+    and a sparse product, a block of entries two `hss_getindex` calls and a sparse gather."""
+
+    def __init__(self, c1, c2, C12, C21, G, opts, dsc):
+        from .hs_oracle_hss import bisect_order
+
+        n1, n2 = c1.n1, c2.n1
+        n = n1 + n2
+        dt = np.result_type(C12.dtype, np.float64)
+        C12, C21 = sp.csr_matrix(C12), sp.csr_matrix(C21)
+        q = bisect_order(G)  # q[new position] = position in [int1; int2]
+        self.q = q
+
+        def mul0(X, trans=False):
+            X1, X2 = X[:n1], X[n1:]
+            if not trans:
+                return np.concatenate([c1.diag_mul(0, X1) + C12 @ X2, C21 @ X1 + c2.diag_mul(0, X2)], axis=0)
+            return np.concatenate([c1.diag_mul(0, X1, True) + C21.T @ X2, C12.T @ X1 + c2.diag_mul(0, X2, True)], axis=0)
+
+        def get0(I, J):
+            out = np.zeros((len(I), len(J)), dtype=dt)
+            i1, i2, j1, j2 = I < n1, I >= n1, J < n1, J >= n1
+            if i1.any() and j1.any():
+                out[np.ix_(i1, j1)] = c1.diag_get(0, I[i1], J[j1])
+            if i2.any() and j2.any():
+                out[np.ix_(i2, j2)] = c2.diag_get(0, I[i2] - n1, J[j2] - n1)
+            if i1.any() and j2.any():
+                out[np.ix_(i1, j2)] = C12[I[i1]][:, J[j2] - n1].toarray()
+            if i2.any() and j1.any():
+                out[np.ix_(i2, j1)] = C21[I[i2] - n1][:, J[j1]].toarray()
+            return out
+
+        def mul(X):  # (M[q, q]) X
+            Y = np.zeros_like(X, dtype=np.result_type(X.dtype, dt))
+            Y[q] = X
+            return mul0(Y)[q]
+
+        def mulT(X):
+            Y = np.zeros_like(X, dtype=np.result_type(X.dtype, dt))
+            Y[q] = X
+            return mul0(Y, True)[q]
+
+        self.H = _compress(Op(n, dt, mul, mulT, lambda I, J: get0(q[I], q[J])), opts, scale=dsc)
+        self.F = HS.rs_factor(self.H)
+        self.hssrank = HS.hssrank(self.H)
+
+    def solve(self, B):
+        X = np.empty(B.shape, dtype=np.result_type(B.dtype, self.H.dtype))
+        X[self.q] = HS.rs_solve(self.F, B[self.q])
+        return X
+
+
 class Node:
     __slots__ = ("D", "L", "R", "S", "int", "bnd", "left", "right", "kind", "n1")
 
@@ -148,11 +203,15 @@ class Node:
         self.D, self.L, self.R, self.S, self.int, self.bnd, self.left, self.right, self.kind, self.n1 = D, L, R, S, int_, bnd, left, right, kind, n1
 
 
-def factor(A, nd, nd_loc, dexp=2, opts=None, **kw):
+def factor(A, nd, nd_loc, dexp=2, dmode="block", opts=None, **kw):
+    """dmode = "block": `D = blockfactor` over the children's HSS blocks (the reference's 2x2 form); "single": `D` as one HSS matrix over
+    a bisection order of the interior graph, compressed matrix-free (the device formulation)."""
     opts = (opts or O.SolverOptions()).copy(**kw)
     O.chkopts(opts)
     swlevel = max(O.depth(nd) + opts.swlevel, 0) if opts.swlevel < 0 else opts.swlevel
-    return _factor(sp.csc_matrix(A), nd, nd_loc, 1, swlevel, opts, 10.0 ** (-dexp))
+    A = sp.csc_matrix(A)
+    _factor.G = sp.csr_matrix((abs(A) + abs(A).T) > 0) if dmode == "single" else None
+    return _factor(A, nd, nd_loc, 1, swlevel, opts, 10.0 ** (-dexp))
 
 
 def _factor(A, nd, nd_loc, level, swlevel, opts, dsc):
@@ -193,7 +252,11 @@ def _factor(A, nd, nd_loc, level, swlevel, opts, dsc):
     # ---- matrix-free branch: both children hand over HSS Schur complements (this includes the root, factorization.jl:67,126)
     c1, c2 = SBlock(Fl.S, Fl.n1), SBlock(Fr.S, Fr.n1)
     g = lambda I, J: A[I - 1][:, J - 1]  # noqa: E731  sparse couplings, 1-based index vectors
-    D = BlockD(c1, c2, g(int1, int2), g(int2, int1), opts, dsc)
+    if getattr(_factor, "G", None) is not None:
+        ids = np.concatenate([int1, int2]) - 1
+        D = SingleD(c1, c2, g(int1, int2), g(int2, int1), _factor.G[ids][:, ids], opts, dsc)
+    else:
+        D = BlockD(c1, c2, g(int1, int2), g(int2, int1), opts, dsc)
     nb1, nb2 = len(bnd1), len(bnd2)
     if nb1 + nb2 == 0:
         return Node(D, None, None, np.zeros((0, 0), A.dtype), nd.int, nd.bnd, Fl, Fr, "mf", n1)
@@ -316,7 +379,7 @@ def maxrank(F):
             r = max(r, maxrank(c))
     if isinstance(F.S, HS.Hss):
         r = max(r, HS.hssrank(F.S))
-    if isinstance(F.D, BlockD):
+    if isinstance(F.D, (BlockD, SingleD)):
         r = max(r, F.D.hssrank)
     for M in (F.L, F.R):
         if isinstance(M, OL.LowRankMatrix):

@@ -37,3 +37,18 @@ def test_exact_when_nothing_is_compressed(hs):
     F = OM.factor(P["A"], P["ond"], P["ond_loc"], swlevel=0)
     assert OM.count_kinds(F) == {"dense": OM.count_kinds(F)["dense"]}
     assert relerr(OM.ldiv(F, P["b"]), spla.splu(P["A"]).solve(P["b"])) < 1e-10
+
+
+def test_single_hss_interior_block_matrix_free(hs):
+    """`D` as ONE HSS matrix over a bisection order, compressed from the children's HSS blocks + sparse couplings without
+    `A11^-1 * A12` (the device formulation of hs_options.hss_d, matrix-free): same accuracy as the reference's 2x2 blockfactor."""
+    P = prepare(hs, (16, 16, 16), rhs="randn", kind="poisson", nmax=64)
+    xr = spla.splu(P["A"]).solve(P["b"])
+    for tol, bound in ((1e-3, 0.2), (1e-8, 1e-5)):
+        kw = dict(dexp=2, swlevel=3, swsize=8, atol=tol, rtol=tol, leafsize=16)
+        Fs = OM.factor(P["A"], P["ond"], P["ond_loc"], dmode="single", **kw)
+        Fb = OM.factor(P["A"], P["ond"], P["ond_loc"], dmode="block", **kw)
+        assert isinstance(Fs.D, OM.SingleD) and isinstance(Fb.D, OM.BlockD)
+        es, eb = relerr(OM.ldiv(Fs, P["b"]), xr), relerr(OM.ldiv(Fb, P["b"]), xr)
+        print(f"tol={tol:g}: single HSS D {es:.2e} (hssrank {Fs.D.hssrank}), 2x2 blockfactor {eb:.2e} (hssrank {Fb.D.hssrank})")
+        assert es < bound and es <= max(30 * eb, bound)
