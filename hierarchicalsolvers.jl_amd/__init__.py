@@ -7,7 +7,7 @@ so import it through ``hsamd`` (repo root) which registers it as
 """
 from .nesteddissection import (  # noqa: F401
     NDNode, isleaf, isbranch, depth, symfact, postorder, postorder_nodes, permuted, invperm,
-    contigious, parse_elimtree, serialize_elimtree, getinterior, getboundary, flatten_tree, native_symbolic,
+    contigious, parse_elimtree, serialize_elimtree, getinterior, getboundary, flatten_tree, native_symbolic, native_graph_symbolic,
 )
 from . import problems  # noqa: F401
 from .solver import SolverOptions, chkopts, factor, factorize, FactorNode, ldiv, maxrank  # noqa: F401,E402

@@ -64,7 +64,7 @@ EXPORTS = [
     "hs_analyze", "hs_plan", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned",
-    "hs_symbolic_from_elimtree", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
+    "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free", "hs_node_schur_hss",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_bisect_perm",
@@ -159,6 +159,8 @@ def lib():
     L.hs_node_info.restype = C.c_int
     L.hs_symbolic_from_elimtree.argtypes = [i64, p_i64, p_i64, p_i64, p_i64, p_i64, i64, p_i64, p_i64, i64, C.POINTER(vp)]
     L.hs_symbolic_from_elimtree.restype = C.c_int
+    L.hs_symbolic_from_graph.argtypes = [i64, p_i64, p_i64, i64, C.POINTER(vp)]
+    L.hs_symbolic_from_graph.restype = C.c_int
     L.hs_symbolic_size.argtypes = [vp]
     L.hs_symbolic_size.restype = i64
     L.hs_symbolic_perm.argtypes = [vp]

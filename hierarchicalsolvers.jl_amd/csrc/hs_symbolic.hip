@@ -194,6 +194,191 @@ extern "C" int hs_symbolic_from_elimtree(int64_t nnodes, const int64_t* fathers,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Nested dissection of a GENERAL sparse matrix from its graph (no coordinates): the elimination tree in the reference's
+// disjoint-ownership form (every DOF in exactly one leaf; bnd(B) = DOFs of B with a neighbour outside B; a parent eliminates
+// (bnd(l) | bnd(r)) - bnd(parent); src/nesteddissection.jl:19-21,105-148).  The reference only CONSUMES such trees -- the
+// generator behind its .mat files is not part of it.  A set is halved by a breadth-first sweep of its induced subgraph from a
+// pseudo-peripheral vertex (first half of the sweep against the rest), until it holds at most nmax DOFs; the result then goes
+// through the same pipeline as a tree read from a file (symfact! -> postorder -> permuted!).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct GNode {
+  int left = -1, right = -1;
+  std::vector<int64_t> in, bd;  // 1-based, ascending
+};
+struct GraphND {
+  int64_t n;
+  std::vector<int64_t> ap;
+  std::vector<int> aj;       // symmetrised pattern without the diagonal, sorted rows
+  std::vector<int> deg, tag, inside, seen, queue;
+  std::vector<GNode> nodes;  // post-order
+  int nmax, stamp = 0, sets = 0;
+
+  // breadth-first order of the vertices of V (all tagged `id`), the component of `start` first, then the others by lowest id
+  void sweep(const std::vector<int>& V, int id, int start, std::vector<int>& order) {
+    ++stamp;
+    order.clear();
+    size_t scan = 0;
+    auto push = [&](int v) {
+      seen[v] = stamp;
+      order.push_back(v);
+    };
+    push(start);
+    size_t head = 0;
+    while (order.size() < V.size()) {
+      if (head == order.size()) {
+        while (seen[V[scan]] == stamp) ++scan;
+        push(V[scan]);
+      }
+      const int v = order[head++];
+      for (int64_t a = ap[v]; a < ap[v + 1]; ++a) {
+        const int w = aj[a];
+        if (tag[w] == id && seen[w] != stamp) push(w);
+      }
+    }
+  }
+  // V ascending; returns the node index; bnd flags of V are left in `isb` (indexed like V)
+  int build(const std::vector<int>& V, std::vector<char>& isb) {
+    const int id = ++sets;
+    for (int v : V) tag[v] = id;
+    isb.assign(V.size(), 0);
+    for (size_t k = 0; k < V.size(); ++k) {
+      const int v = V[k];
+      int in = 0;
+      for (int64_t a = ap[v]; a < ap[v + 1]; ++a) in += tag[aj[a]] == id;
+      isb[k] = deg[v] > in;
+    }
+    GNode g;
+    if ((int)V.size() <= nmax || V.size() < 2) {
+      for (size_t k = 0; k < V.size(); ++k) (isb[k] ? g.bd : g.in).push_back((int64_t)V[k] + 1);
+      nodes.push_back(g);
+      return (int)nodes.size() - 1;
+    }
+    std::vector<int> order;
+    int start = V[0];
+    for (int rep = 0; rep < 2; ++rep) {  // pseudo-peripheral vertex: the last vertex of the first component's sweep, twice
+      ++stamp;
+      std::vector<int> comp{start};
+      seen[start] = stamp;
+      for (size_t head = 0; head < comp.size(); ++head) {
+        const int v = comp[head];
+        for (int64_t a = ap[v]; a < ap[v + 1]; ++a) {
+          const int w = aj[a];
+          if (tag[w] == id && seen[w] != stamp) {
+            seen[w] = stamp;
+            comp.push_back(w);
+          }
+        }
+      }
+      start = comp.back();
+    }
+    sweep(V, id, start, order);
+    const size_t half = (V.size() + 1) / 2;
+    std::vector<int> V1(order.begin(), order.begin() + half), V2(order.begin() + half, order.end());
+    std::sort(V1.begin(), V1.end());
+    std::sort(V2.begin(), V2.end());
+    std::vector<char> b1, b2;
+    const int l = build(V1, b1);
+    const int r = build(V2, b2);
+    // the children re-tagged their vertices; this node's own boundary flags were computed before
+    std::vector<char> cb(V.size(), 0);
+    {
+      size_t i1 = 0, i2 = 0;
+      for (size_t k = 0; k < V.size(); ++k) {
+        if (i1 < V1.size() && V1[i1] == V[k]) cb[k] = b1[i1++];
+        else cb[k] = b2[i2++];
+      }
+    }
+    for (size_t k = 0; k < V.size(); ++k) {
+      if (isb[k]) g.bd.push_back((int64_t)V[k] + 1);
+      else if (cb[k]) g.in.push_back((int64_t)V[k] + 1);
+    }
+    g.left = l;
+    g.right = r;
+    nodes.push_back(g);
+    return (int)nodes.size() - 1;
+  }
+};
+}  // namespace
+
+extern "C" int hs_symbolic_from_graph(int64_t n, const int64_t* colptr, const int64_t* rowval, int64_t nmax, hs_symbolic** out) {
+  if (out) *out = nullptr;
+  try {
+    if (!out || n <= 0 || !colptr || !rowval || nmax < 1) SYM_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_symbolic_from_graph needs a pattern and nmax >= 1");
+    if (n > 2000000000LL) SYM_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: more than 2^31 DOFs");
+    GraphND G;
+    G.n = n;
+    G.nmax = (int)std::min<int64_t>(nmax, n);
+    // symmetrised pattern without the diagonal
+    std::vector<int64_t> cnt((size_t)n + 1, 0);
+    const int64_t nnz = colptr[n] - 1;
+    for (int64_t c = 0; c < n; ++c)
+      for (int64_t a = colptr[c] - 1; a < colptr[c + 1] - 1; ++a) {
+        const int64_t r = rowval[a] - 1;
+        if (r < 0 || r >= n) SYM_FAIL(HS_ERR_DIMENSION, a, "BoundsError: row index %lld outside 1:%lld", (long long)(r + 1), (long long)n);
+        if (r == c) continue;
+        cnt[(size_t)r + 1]++;
+        cnt[(size_t)c + 1]++;
+      }
+    (void)nnz;
+    for (int64_t i = 0; i < n; ++i) cnt[(size_t)i + 1] += cnt[(size_t)i];
+    std::vector<int> adj((size_t)cnt[(size_t)n]);
+    std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+    for (int64_t c = 0; c < n; ++c)
+      for (int64_t a = colptr[c] - 1; a < colptr[c + 1] - 1; ++a) {
+        const int64_t r = rowval[a] - 1;
+        if (r == c) continue;
+        adj[(size_t)pos[(size_t)r]++] = (int)c;
+        adj[(size_t)pos[(size_t)c]++] = (int)r;
+      }
+    G.ap.assign((size_t)n + 1, 0);
+    G.aj.reserve(adj.size());
+    for (int64_t v = 0; v < n; ++v) {
+      auto b = adj.begin() + cnt[(size_t)v], e = adj.begin() + cnt[(size_t)v + 1];
+      std::sort(b, e);
+      e = std::unique(b, e);
+      G.aj.insert(G.aj.end(), b, e);
+      G.ap[(size_t)v + 1] = (int64_t)G.aj.size();
+    }
+    G.deg.resize((size_t)n);
+    for (int64_t v = 0; v < n; ++v) G.deg[(size_t)v] = (int)(G.ap[(size_t)v + 1] - G.ap[(size_t)v]);
+    G.tag.assign((size_t)n, 0);
+    G.seen.assign((size_t)n, 0);
+    std::vector<int> all((size_t)n);
+    for (int64_t v = 0; v < n; ++v) all[(size_t)v] = (int)v;
+    std::vector<char> isb;
+    G.build(all, isb);
+    // the 7 arrays of util/read_problem.jl:14-20, nodes in post-order
+    const int nn = (int)G.nodes.size();
+    std::vector<int64_t> fathers(nn, -1), lsons(nn, -1), rsons(nn, -1), ninter(nn), nbound(nn);
+    int64_t mi = 1, mb = 1;
+    for (int i = 0; i < nn; ++i) {
+      ninter[i] = (int64_t)G.nodes[i].in.size();
+      nbound[i] = (int64_t)G.nodes[i].bd.size();
+      mi = std::max(mi, ninter[i]);
+      mb = std::max(mb, nbound[i]);
+      if (G.nodes[i].left >= 0) {
+        lsons[i] = G.nodes[i].left + 1;
+        rsons[i] = G.nodes[i].right + 1;
+        fathers[G.nodes[i].left] = i + 1;
+        fathers[G.nodes[i].right] = i + 1;
+      }
+    }
+    std::vector<int64_t> inter((size_t)mi * nn, 0), bound((size_t)mb * nn, 0);
+    for (int i = 0; i < nn; ++i) {
+      std::copy(G.nodes[i].in.begin(), G.nodes[i].in.end(), inter.begin() + (size_t)mi * i);
+      std::copy(G.nodes[i].bd.begin(), G.nodes[i].bd.end(), bound.begin() + (size_t)mb * i);
+    }
+    return hs_symbolic_from_elimtree(nn, fathers.data(), lsons.data(), rsons.data(), ninter.data(), inter.data(), mi, nbound.data(), bound.data(), mb, out);
+  } catch (const SymErr& e) {
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    hs_set_error(HS_ERR_NOMEM, 0, "host allocation failed");
+    return HS_ERR_NOMEM;
+  }
+}
+
 extern "C" int64_t hs_symbolic_size(const hs_symbolic* S) { return S ? S->n : 0; }
 extern "C" const int64_t* hs_symbolic_perm(const hs_symbolic* S) { return S ? S->perm.data() : nullptr; }
 extern "C" int hs_symbolic_tree(const hs_symbolic* S, hs_tree* t) {

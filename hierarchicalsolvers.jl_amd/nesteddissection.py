@@ -31,6 +31,7 @@ __all__ = [
     "getboundary",
     "flatten_tree",
     "native_symbolic",
+    "native_graph_symbolic",
 ]
 
 
@@ -286,6 +287,51 @@ def flatten_tree(nd, nd_loc):
     )
 
 
+def _symbolic_result(L, h):
+    import ctypes as C  # noqa: F401
+
+    from . import _lib
+
+    try:
+        n = int(L.hs_symbolic_size(h))
+        perm = np.ctypeslib.as_array(L.hs_symbolic_perm(h), shape=(n,)).copy() if n else np.zeros(0, np.int64)
+        t = _lib.hs_tree()
+        _lib.check(L.hs_symbolic_tree(h, C.byref(t)))
+        k = int(t.nnodes)
+
+        def arr(ptr, m):
+            return np.ctypeslib.as_array(ptr, shape=(m,)).copy() if m else np.zeros(0, np.int64)
+
+        tree = dict(nnodes=k, left=arr(t.left, k), right=arr(t.right, k))
+        for name in ("int", "bnd", "iloc", "bloc"):
+            ptr = arr(getattr(t, name + "_ptr"), k + 1)
+            tree[name + "_ptr"] = ptr
+            tree[name + "_idx"] = arr(getattr(t, name + "_idx"), int(ptr[-1]))
+    finally:
+        L.hs_symbolic_free(h)
+    return tree, perm
+
+
+def native_graph_symbolic(A, nmax=100):
+    """Nested dissection of a general sparse matrix from its graph, then ``symfact!`` -> ``postorder`` -> ``permuted!``, all in the C++
+    symbolic layer (``hs_symbolic_from_graph``, include/hs_symbolic.h).  Returns ``(tree, perm)`` like :func:`native_symbolic`.
+    The Python mirror of the tree builder is ``problems.graph_nested_dissection``.  No GPU needed."""
+    import ctypes as C
+
+    import scipy.sparse as sp
+
+    from . import _lib
+
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    colptr = np.ascontiguousarray(A.indptr, dtype=np.int64) + 1
+    rowval = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.hs_symbolic_from_graph(A.shape[0], colptr.ctypes.data_as(_lib.p_i64), rowval.ctypes.data_as(_lib.p_i64), int(nmax), C.byref(h)))
+    return _symbolic_result(L, h)
+
+
 def native_symbolic(fathers, lsons, rsons, ninter, inter, nbound, bound):
     """The whole host pipeline of the reference's scenario (``parse_elimtree`` -> ``symfact!`` -> ``postorder`` ->
     ``permuted!(nd, invperm(perm))``, test/rungmres.jl:15-19) in the C++ symbolic layer (``include/hs_symbolic.h``).
@@ -310,21 +356,4 @@ def native_symbolic(fathers, lsons, rsons, ninter, inter, nbound, bound):
     p = lambda a: a.ctypes.data_as(_lib.p_i64)  # noqa: E731
     _lib.check(L.hs_symbolic_from_elimtree(nn, p(fathers), p(lsons), p(rsons), p(ninter), p(inter), inter.shape[0], p(nbound), p(bound),
                                            bound.shape[0], C.byref(h)))
-    try:
-        n = int(L.hs_symbolic_size(h))
-        perm = np.ctypeslib.as_array(L.hs_symbolic_perm(h), shape=(n,)).copy() if n else np.zeros(0, np.int64)
-        t = _lib.hs_tree()
-        _lib.check(L.hs_symbolic_tree(h, C.byref(t)))
-        k = int(t.nnodes)
-
-        def arr(ptr, m):
-            return np.ctypeslib.as_array(ptr, shape=(m,)).copy() if m else np.zeros(0, np.int64)
-
-        tree = dict(nnodes=k, left=arr(t.left, k), right=arr(t.right, k))
-        for name in ("int", "bnd", "iloc", "bloc"):
-            ptr = arr(getattr(t, name + "_ptr"), k + 1)
-            tree[name + "_ptr"] = ptr
-            tree[name + "_idx"] = arr(getattr(t, name + "_idx"), int(ptr[-1]))
-    finally:
-        L.hs_symbolic_free(h)
-    return tree, perm
+    return _symbolic_result(L, h)

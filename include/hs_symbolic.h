@@ -23,6 +23,12 @@ int hs_symbolic_from_elimtree(int64_t nnodes, const int64_t* fathers, const int6
                               const int64_t* ninter, const int64_t* inter, int64_t ld_inter,
                               const int64_t* nbound, const int64_t* bound, int64_t ld_bound, hs_symbolic** out);
 
+/* The same from the GRAPH of a general sparse matrix alone (1-based CSC pattern colptr[n+1], rowval[nnz]; the values are not needed): nested
+ * dissection by recursive breadth-first bisection into the reference's disjoint-ownership tree (every DOF in exactly one leaf of at most
+ * nmax DOFs; bnd(B) = DOFs of B with a neighbour outside B), then symfact! -> postorder -> permuted!.  The reference only consumes such trees
+ * (src/nesteddissection.jl:105-148); the generator behind its .mat files is not part of it. */
+int hs_symbolic_from_graph(int64_t n, const int64_t* colptr, const int64_t* rowval, int64_t nmax, hs_symbolic** out);
+
 int64_t hs_symbolic_size(const hs_symbolic* S);        /* number of DOFs n */
 const int64_t* hs_symbolic_perm(const hs_symbolic* S); /* n entries, 1-based: factor A[perm, perm] (postorder, :73-79) */
 /* the flat post-ordered tree in the PERMUTED numbering (what symfact! + permuted! leave in nd, nd_loc): valid for

@@ -99,3 +99,37 @@ def test_graph_nd_factorization_on_gpu(hs, complex_):
     # compressed fronts on the same tree: a preconditioner-quality solve
     Fc = hs.factor(Ap, nd, nd_loc, swlevel=3, swsize=8, atol=1e-6, rtol=1e-6)
     assert np.linalg.norm(hs.ldiv(Fc, b) - xr) / np.linalg.norm(xr) < 1e-3
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_native_graph_nd_matches_the_python_mirror(hs, complex_):
+    """`hs_symbolic_from_graph` (C++: graph -> tree -> symfact! -> postorder -> permuted!) against the Python pipeline on the same
+    matrix: same elimination order, same flat tree; and the oracle's factorization on it is exact."""
+    A = unstructured_problem(900, seed=4, complex_=complex_)
+    tree, perm = hs.native_graph_symbolic(A, nmax=50)
+    nd = hs.problems.graph_nested_dissection(A, nmax=50)
+    nd2, nd_loc = hs.symfact(nd)
+    perm_py = hs.postorder(nd2)
+    assert np.array_equal(perm, perm_py)
+    flat = hs.flatten_tree(hs.permuted(nd2, hs.invperm(perm_py)), nd_loc)
+    assert tree["nnodes"] == flat["nnodes"]
+    for k in ("left", "right", "int_ptr", "int_idx", "bnd_ptr", "bnd_idx", "iloc_ptr", "iloc_idx", "bloc_ptr", "bloc_idx"):
+        assert np.array_equal(np.asarray(tree[k]), np.asarray(flat[k])), k
+    assert sorted(perm.tolist()) == list(range(1, A.shape[0] + 1))
+    # a grid matrix too, and argument errors
+    G = hs.problems.grid_matrix((9, 8, 7), "poisson")
+    t2, p2 = hs.native_graph_symbolic(G, nmax=40)
+    assert sorted(p2.tolist()) == list(range(1, G.shape[0] + 1)) and t2["nnodes"] >= 15
+    with pytest.raises(ValueError):
+        hs.native_graph_symbolic(G, nmax=0)
+
+
+@pytest.mark.gpu
+def test_native_graph_nd_factorization_on_gpu(hs):
+    A = unstructured_problem(2500, seed=5)
+    tree, perm = hs.native_graph_symbolic(A, nmax=80)
+    Ap = A[perm - 1][:, perm - 1].tocsc()
+    b = np.random.default_rng(6).standard_normal(A.shape[0])
+    F = hs.factor(Ap, tree, None, swlevel=0)
+    x = hs.ldiv(F, b)
+    assert np.linalg.norm(x - spla.splu(Ap).solve(b)) / np.linalg.norm(b) < 1e-10
