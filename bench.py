@@ -240,6 +240,7 @@ def main():
                             "frac_of_measured_copy_bw_6290GBps": gbs / 6290.0}
         if roofline:
             out["roofline"] = roofline
+            out["mfma_util_pct"] = 100.0 * roofline["frac"]  # BASELINE.json's metric pairs the time with the MFMA utilisation (FP64-matrix peak 78.6 TF)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(st["flops_factor"], args.cpu_sample, is_c)
         print(json.dumps(out))
