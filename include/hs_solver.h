@@ -62,7 +62,9 @@ typedef struct hs_options {
   uint8_t hss_d;      /* > 0: a front at a level <= swlevel whose interior block has at least hss_d*1024 DOFs keeps D = Aii as an HSS
                          matrix (include/hs_hss.h) instead of a dense LU -- the role of `D::BlockFactorization` over HssMatrix blocks
                          (blockmatrix.jl:121-130, factorization.jl:86-96); the root included, which in the reference receives its
-                         children's HSS blocks although it is never flagged (factorization.jl:15,67,126).  Single rank only. */
+                         children's HSS blocks although it is never flagged (factorization.jl:15,67,126).  Single rank only.  With such fronts
+                         hs_ldiv_dev_* and hs_solve_*_levels return only after the HSS solves on the given stream have completed
+                         (the HSS module recycles its workspaces per call). */
   uint8_t hss_dexp;   /* tolerance of that HSS form: atol, rtol * 10^-e with e = 2 for hss_dexp = 0 (default) and e = hss_dexp - 1
                          otherwise (1: the tolerance of the fronts, as the reference does).  D^-1 inherits cond(D) * tol, the low-rank
                          couplings only tol: measured on Poisson 128^3 the same tolerance for both leaves GMRES unconverged */
