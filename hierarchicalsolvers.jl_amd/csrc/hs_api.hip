@@ -180,6 +180,8 @@ struct hs_handle {
   bool optimistic = true;   // HS_OPTIMISTIC=0 turns it off; a level that had to be redone turns it off for the rest of the handle's life
   int* d_own = nullptr;
   int* d_pos = nullptr;
+  int* d_owned = nullptr;   // 0-based ids of the DOFs this rank eliminates (hs_extract_owned: one launch)
+  int64_t n_owned = 0;
   int64_t* d_colptr = nullptr;
   int32_t* d_rowval = nullptr;
   void* d_nz = nullptr;
@@ -220,7 +222,7 @@ static void free_handle(hs_handle* h) {
   free_hss_any(h);
   free_lowrank_any(h);
   void* ptrs[] = {h->d_fac,   h->d_inv, h->d_sb,    h->d_int, h->d_tmpi, h->d_colptr, h->d_rowval, h->d_nz,
-                  h->d_nodes, h->d_sc,  h->d_solve, h->d_w1,  h->d_w2,   h->d_part,   h->d_b};
+                  h->d_nodes, h->d_sc,  h->d_solve, h->d_w1,  h->d_w2,   h->d_part,   h->d_b,   h->d_owned};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -333,7 +335,9 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr, const SplitTr
     x.oni = x.ni; x.oni1 = x.ni1; x.onb1 = x.nb1;
   }
   // every DOF is eliminated at most once; the reference concatenates child Schur complements, it
-  // never extend-adds (factorization.jl:118-121), so fronts of unrelated nodes are disjoint
+  // never extend-adds (factorization.jl:118-121), so fronts of unrelated nodes must be disjoint: the fronts of one
+  // level are assembled by the same grouped launches (mark / gather write own[g], pos[g] per DOF of [int; bnd]), so a
+  // DOF shared by two fronts of a level (a vertex-separator tree) or listed twice in one front is rejected here
   {
     std::vector<char> seen(n, 0);
     for (int i = 0; i < nn; ++i)
@@ -341,6 +345,17 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr, const SplitTr
         int g = F[N[i].off_fidx + e];
         if (seen[g]) HS_FAIL(HS_ERR_DIMENSION, i, "DimensionMismatch: DOF %d is interior to two nodes", g + 1);
         seen[g] = 1;
+      }
+    std::vector<int> lastlv(n, -1), lastnode(n, -1);
+    for (int i = 0; i < nn; ++i)
+      for (int e = 0; e < N[i].m; ++e) {
+        int g = F[N[i].off_fidx + e];
+        if (lastnode[g] == i) HS_FAIL(HS_ERR_DIMENSION, i, "DimensionMismatch: DOF %d is listed twice in the front [int; bnd] of node %d", g + 1, i);
+        if (lastlv[g] == N[i].level)
+          HS_FAIL(HS_ERR_DIMENSION, i, "DimensionMismatch: DOF %d belongs to the fronts of nodes %d and %d of the same tree level (fronts of a level must be disjoint)",
+                  g + 1, lastnode[g], i);
+        lastlv[g] = N[i].level;
+        lastnode[g] = i;
       }
   }
   // pseudo-node: the root's own boundary (normally empty) is eliminated last, `F.S \ C[F.bnd,:]` (factornode.jl:72)
@@ -680,6 +695,14 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         for (int e = 0; e < x.oni; ++e) sp[np[e]] = e;
       }
       HS_HIP(hipMemcpy(dint, hint.data(), ints * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (nranks > 1) {  // the DOFs this rank eliminates, as one index list
+      std::vector<int> owned;
+      for (int i = 0; i < h->nnodes; ++i)
+        if (N[i].mine) owned.insert(owned.end(), h->fidx_host.begin() + N[i].off_fidx, h->fidx_host.begin() + N[i].off_fidx + N[i].ni);
+      h->n_owned = (int64_t)owned.size();
+      dmalloc((void**)&h->d_owned, owned.size() * sizeof(int), "owned index list");
+      if (!owned.empty()) HS_HIP(hipMemcpy(h->d_owned, owned.data(), owned.size() * sizeof(int), hipMemcpyHostToDevice));
     }
 
     // ---- device descriptors (built once; pointers are fixed from here on) ------------------------------------
@@ -1181,29 +1204,29 @@ static void set_schur_buffer(hs_handle* h, int node, void* dptr) {
   }
 }
 extern "C" int hs_set_schur_buffer(hs_handle* h, int64_t node, void* dptr) {
-  HS_GUARD(check_handle(h); if (node < 0 || node >= h->nnodes || !dptr) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+  HS_GUARD(check_device_handle(h); if (node < 0 || node >= h->nnodes || !dptr) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
            if (h->is_complex) set_schur_buffer<cplx>(h, (int)node, dptr); else set_schur_buffer<double>(h, (int)node, dptr));
 }
 // buf[j] = b[bnd_j(node)] and back: the boundary segment of a front as a contiguous vector
 extern "C" int hs_pack_bnd(const hs_handle* h, int64_t node, const void* d_b, void* d_buf, void* stream) {
-  HS_GUARD(check_handle(h); if (node < 0 || node >= h->nnodes) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+  HS_GUARD(check_device_handle(h); if (node < 0 || node >= h->nnodes) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
            const NodeH& x = h->nodes[node];
            launch_pack_idx(h->d_int + x.off_fidx + x.ni, x.nb, d_b, d_buf, h->is_complex ? 16 : 8, (hipStream_t)stream));
 }
 extern "C" int hs_unpack_bnd(const hs_handle* h, int64_t node, void* d_b, const void* d_buf, void* stream) {
-  HS_GUARD(check_handle(h); if (node < 0 || node >= h->nnodes) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+  HS_GUARD(check_device_handle(h); if (node < 0 || node >= h->nnodes) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
            const NodeH& x = h->nodes[node];
            launch_unpack_idx(h->d_int + x.off_fidx + x.ni, x.nb, d_b, d_buf, h->is_complex ? 16 : 8, (hipStream_t)stream));
 }
 // d_out (zero-filled by the caller) receives the solution entries this rank owns: out[int(node)] = b[int(node)]
 extern "C" int hs_extract_owned(const hs_handle* h, const void* d_b, void* d_out, void* stream) {
-  HS_GUARD(check_handle(h); const int esz = h->is_complex ? 16 : 8; for (int i = 0; i < h->nnodes; ++i) {
-    const NodeH& x = h->nodes[i];
-    if (!x.mine || x.ni == 0) continue;
-    char* tmp = (char*)h->d_w1 + (size_t)x.woff * esz;
-    launch_pack_idx(h->d_int + x.off_fidx, x.ni, d_b, tmp, esz, (hipStream_t)stream);
-    launch_unpack_idx(h->d_int + x.off_fidx, x.ni, d_out, tmp, esz, (hipStream_t)stream);
-  });
+  HS_GUARD(check_device_handle(h); const int esz = h->is_complex ? 16 : 8;
+           if (h->d_owned) { launch_copy_idx(h->d_owned, (int)h->n_owned, d_b, d_out, esz, (hipStream_t)stream); return HS_OK; }
+           for (int i = 0; i < h->nnodes; ++i) {  // single rank: every DOF is owned
+             const NodeH& x = h->nodes[i];
+             if (!x.mine || x.ni == 0) continue;
+             launch_copy_idx(h->d_int + x.off_fidx, x.ni, d_b, d_out, esz, (hipStream_t)stream);
+           });
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -224,6 +224,7 @@ template <class T>
 void launch_lr_trap(const T* Lp, int ldp, int rows, int r, const int* rp, const T* t, T* dst, const int* didx, hipStream_t s);
 void launch_pack_idx(const int* idx, int cnt, const void* b, void* buf, int esz, hipStream_t s);    // buf[i] = b[idx[i]]
 void launch_unpack_idx(const int* idx, int cnt, void* b, const void* buf, int esz, hipStream_t s);  // b[idx[i]] = buf[i]
+void launch_copy_idx(const int* idx, int cnt, const void* b, void* out, int esz, hipStream_t s);      // out[idx[i]] = b[idx[i]]
 
 void hs_set_error(int code, long long info, const char* fmt, ...);
 

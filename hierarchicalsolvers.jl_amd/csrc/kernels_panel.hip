@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
     for (int i = 0; i < HS_PB; ++i)
       if (i <= j) s = Scal<T>::fma(a[i], s_iu[i + j * HS_PB], s);
     l[j] = s;
-    lmax = fmax(lmax, Scal<T>::abs1(s));
+    if (!(Scal<T>::abs1(s) <= HS_GROWTH_MAX)) lmax = 2.0 * HS_GROWTH_MAX;  // not fmax(): it drops NaN operands, and a NaN multiplier is a violation
     if (j < w) base[(size_t)j * nd.ldl] = s;
   }
   // fuse & 4: optimistic pivoting -- a row that partial pivoting could have picked (row < pivrows) must not need a

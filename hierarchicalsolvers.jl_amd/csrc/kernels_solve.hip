@@ -218,6 +218,19 @@ __global__ __launch_bounds__(256) void unpack_idx_kernel(const int* __restrict__
   const double* s = reinterpret_cast<const double*>(buf + (size_t)i * esz);
   for (int k = 0; k < esz / 8; ++k) d[k] = s[k];
 }
+// out[idx[i]] = b[idx[i]]: the entries of the solution one rank owns, in one launch over a precomputed index list
+__global__ __launch_bounds__(256) void copy_idx_kernel(const int* __restrict__ idx, int cnt, const char* __restrict__ b, char* __restrict__ out, int esz) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cnt) return;
+  const size_t o = (size_t)idx[i] * esz;
+  const double* s = reinterpret_cast<const double*>(b + o);
+  double* d = reinterpret_cast<double*>(out + o);
+  for (int k = 0; k < esz / 8; ++k) d[k] = s[k];
+}
+void launch_copy_idx(const int* idx, int cnt, const void* b, void* out, int esz, hipStream_t s) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(copy_idx_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, idx, cnt, (const char*)b, (char*)out, esz);
+}
 void launch_pack_idx(const int* idx, int cnt, const void* b, void* buf, int esz, hipStream_t s) {
   if (cnt <= 0) return;
   hipLaunchKernelGGL(pack_idx_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, idx, cnt, (const char*)b, (char*)buf, esz);

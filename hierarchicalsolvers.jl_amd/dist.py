@@ -105,6 +105,8 @@ class TorchComm:
 def run_numeric(backend, plan, rank, comm):
     """Numeric factorization: rank-local subtrees, then the fronts above the cut level by level,
     receiving the remote child's Schur complement before each join."""
+    if plan.nranks > 1:
+        backend.comm_sync()  # a send of the previous factorization may still read a Schur buffer this one overwrites
     backend.numeric_begin()
     L, cut = plan.nlevels, plan.cut_level
     backend.numeric_levels(L, cut)
@@ -113,6 +115,7 @@ def run_numeric(backend, plan, rank, comm):
             if e["src"] == rank:
                 backend.sync()
                 comm.send(backend.schur_tensor(e["node"]), e["dst"])
+                backend.comm_sync()  # the communicator's stream is unknown to the library: the buffer is free again after this
             elif e["dst"] == rank:
                 comm.recv(backend.schur_tensor(e["node"]), e["src"])
                 backend.comm_sync()
@@ -131,6 +134,7 @@ def run_solve(backend, plan, rank, comm, b):
                 buf = backend.pack_bnd(e["node"], b)
                 backend.sync()
                 comm.send(buf, e["dst"])
+                backend.comm_sync()  # the next pack of this buffer must not overtake the send
             elif e["dst"] == rank:
                 buf = backend.bnd_buffer(e["node"])
                 comm.recv(buf, e["src"])
@@ -145,6 +149,7 @@ def run_solve(backend, plan, rank, comm, b):
                 buf = backend.pack_bnd(e["node"], b)
                 backend.sync()
                 comm.send(buf, e["src"])
+                backend.comm_sync()
             elif e["src"] == rank:
                 buf = backend.bnd_buffer(e["node"])
                 comm.recv(buf, e["dst"])
@@ -241,6 +246,9 @@ class HipBackend:
         self.values = values
 
     def numeric_begin(self):
+        # hs_numeric_begin copies `values` on the library's own stream, which is ordered against the legacy default stream
+        # only: whatever produced `values` on the caller's current torch stream must have finished first
+        self.torch.cuda.current_stream(self.device).synchronize()
         _lib.check(self.L.hs_numeric_begin(self._h, C.c_void_p(self.values.data_ptr()), 1))
 
     def numeric_levels(self, lv_from, lv_to):

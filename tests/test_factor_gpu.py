@@ -216,10 +216,15 @@ def test_optimistic_pivoting_detection(hs, monkeypatch):
     rng = np.random.default_rng(3)
     ni, nb = 200, 70
     m = ni + nb
-    for dominant in (True, False):
+    for dominant in (True, False, "nan", "inf"):
         F = np.asfortranarray(rng.standard_normal((m, m)))
         if dominant:
             F[np.arange(m), np.arange(m)] += 4.0 * np.sqrt(m)
+        if dominant == "nan":  # a NaN multiplier must raise the flag too (fmax() would have dropped it)
+            F[40, 3] = np.nan
+        if dominant == "inf":  # inf - inf inside the multiplier's dot product
+            F[40, 3] = np.inf
+            F[40, 4] = -np.inf
         outLF = np.zeros((m, ni), order="F")
         outUR = np.zeros((ni, nb), order="F")
         outSB = np.zeros((nb, nb), order="F")
@@ -228,7 +233,7 @@ def test_optimistic_pivoting_detection(hs, monkeypatch):
         ms = C.c_double(0)
         p = lambda a: a.ctypes.data_as(_lib.p_f64)  # noqa: E731
         _lib.check(L.hsk_front_factor_d(1, ni, nb, p(F), p(outLF), p(outUR), p(outSB), rp.ctypes.data_as(_lib.p_i64), info.ctypes.data_as(_lib.p_i64), C.byref(ms)))
-        if dominant:
+        if dominant is True:
             assert info[0] == 0
             S = F[ni:, ni:] - F[ni:, :ni] @ np.linalg.solve(F[:ni, :ni], F[:ni, ni:])
             assert relerr(outSB, S) < 1e-11

@@ -210,3 +210,30 @@ def test_hss_block_order_is_a_compact_bisection(hs):
     assert mean_boundary(np.arange(n), 256) > 250
     assert mean_boundary(pos, 256) < 110
     assert L.hsk_bisect_perm(n, None, None, n, ids.ctypes.data_as(hs._lib.p_i64), perm.ctypes.data_as(hs._lib.p_i64)) == hs._lib.HS_ERR_ARGUMENT
+
+
+def test_plan_rejects_fronts_of_a_level_that_share_a_dof(hs):
+    """The fronts of one tree level are assembled by the same grouped launches: a DOF in the [int; bnd] of two same-level
+    fronts (a vertex-separator tree) or listed twice in one front must be refused, not raced on (host-only plan)."""
+    A, b, nd = hs.problems.make_problem((9, 9), kind="poisson", nmax=10)
+    tree, perm = hs.native_symbolic(*hs.serialize_elimtree(nd))
+    Ap = A[perm - 1][:, perm - 1].tocsc()
+    h = hs.dist.plan_only(Ap, tree, None)  # the honest tree is accepted
+    hs._lib.lib().hs_free(h)
+    leaves = [i for i in range(tree["nnodes"]) if tree["left"][i] < 0]
+    a, c = leaves[0], leaves[1]
+
+    def with_extra_bnd(node, dof):
+        """`node` lists one more boundary DOF that its parent never maps (symfact! would drop it): every per-node check passes."""
+        t = {k: np.array(v, copy=True) if isinstance(v, np.ndarray) else v for k, v in tree.items()}
+        at = t["bnd_ptr"][node + 1]
+        t["bnd_idx"] = np.insert(t["bnd_idx"], at, dof)
+        t["bnd_ptr"][node + 1 :] += 1
+        return t
+
+    ya = tree["bnd_idx"][tree["bnd_ptr"][a]]
+    with pytest.raises(hs.DimensionMismatch, match="same tree level"):
+        hs.dist.plan_only(Ap, with_extra_bnd(c, ya), None)  # a boundary DOF of leaf a also in leaf c's front
+    yc = tree["bnd_idx"][tree["bnd_ptr"][c]]
+    with pytest.raises(hs.DimensionMismatch, match="listed twice"):
+        hs.dist.plan_only(Ap, with_extra_bnd(c, yc), None)
