@@ -10,8 +10,13 @@ resident in HBM when the timed region starts.  Metric (BASELINE.json): factorize
 elimination tree per rank, Schur complements sent point-to-point at the joins, RCCL over xGMI).
 
 One JSON line on rank 0.  ``roofline`` describes the dominant kernel (the FP64 MFMA GEMM): achieved =
-its executed flops / its HIP-event time over the timed region's last step.  ``cpu_baseline`` times the
-NumPy oracle (a port of the reference's algorithm, redundant LUs included) on a bounded sample.
+its executed flops / its HIP-event time over one extra profiled step; ``traffic`` = measured HBM bytes per launch from a
+committed PMC pass of THIS round whose launch count equals the run's (else null, with the reason).  ``cpu_baseline``
+times the NumPy oracle (a port of the reference's algorithm, redundant LUs included) and SuperLU on a bounded sample,
+in the sample's own seconds -- nothing is extrapolated -- next to this library's time on the same sample.
+``factor_oneshot_s`` is the one-shot ``factor`` from host arrays (analysis + numeric), what the Julia shim binds.
+``metric_workload`` (N = 1) repeats the measurement on BASELINE.json's own workload class: complex 3-D Helmholtz with
+the fronts compressed at tolerance 1e-4 (the largest such problem that fits one GPU).
 """
 import argparse
 import json
@@ -25,9 +30,22 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_DATASHEET = 78.6  # TFLOP/s, AMD MI355X datasheet (FP64 matrix); the guides list no f64 row
 
 
-def cpu_baseline(flops_full, sample="poisson3d_32", complex_=False):
-    """Oracle (port of the reference's algorithm) timed on the host cores on a bounded sample."""
+def _prepare(hs, name):
+    import numpy as np  # noqa: F401
+
+    A, b, nd = hs.problems.make_problem(name, rhs="randn")
+    nd, nd_loc = hs.symfact(nd)
+    perm = hs.postorder(nd)
+    Ap = A[perm - 1][:, perm - 1].tocsc()
+    nd = hs.permuted(nd, hs.invperm(perm))
+    return Ap, b[perm - 1], nd, nd_loc
+
+
+def cpu_baseline(sample="poisson3d_32", dev=None):
+    """The oracle (port of the reference's algorithm, redundant LUs included) and SuperLU timed on the host cores on a
+    bounded sample, in the sample's own seconds; the GPU path on the SAME sample beside them.  Nothing is extrapolated."""
     import numpy as np
+    import scipy.sparse.linalg as spla
 
     import hsamd
     from oracle import hs_oracle as O
@@ -39,26 +57,124 @@ def cpu_baseline(flops_full, sample="poisson3d_32", complex_=False):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    A, b, nd = hs.problems.make_problem(sample)
+    A, b, nd = hs.problems.make_problem(sample, rhs="randn")
     o = O.parse_elimtree(*hs.serialize_elimtree(nd))
     o, o_loc = O.symfact(o)
     perm = O.postorder(o)
     Ap = A[perm - 1][:, perm - 1].tocsc()
     o = O.permuted(o, O.invperm(perm))
-    fl = O.tree_flops(o) * (4 if complex_ else 1)
+    bp = b[perm - 1]
+    is_c = np.iscomplexobj(Ap.data)
+    fl = O.tree_flops(o) * (4 if is_c else 1)
     t0 = time.perf_counter()
     F = O.factor(Ap, o, o_loc, swlevel=0)
-    x = O.ldiv(F, b[perm - 1])
+    x = O.ldiv(F, bp)
     dt = time.perf_counter() - t0
+    del F
     assert np.isfinite(x).all()
-    return {
-        "value": dt * flops_full / fl,
-        "unit": "s (extrapolated to the full workload by minimal-flop ratio)",
+    out = {
+        "value": dt,
+        "unit": "s (factor + ldiv! of the sample workload; not extrapolated)",
         "cores": int(cores),
         "kind": "port",
-        "sample": f"oracle factor+ldiv on {sample} (n={A.shape[0]}, {fl:.3g} minimal flops) took {dt:.2f} s = {fl / dt / 1e9:.2f} GFLOP/s",
-        "sample_seconds": dt,
+        "sample": f"oracle factor+ldiv on {sample} (n={A.shape[0]}, {fl:.3g} minimal flops): {dt:.2f} s = {fl / dt / 1e9:.2f} GFLOP/s on the minimal count, BLAS threads = {cores}",
+        "sample_workload": sample,
+        "sample_minimal_flops": fl,
     }
+    # external yardstick: SuperLU factor + solve of the same matrix, single-threaded
+    t0 = time.perf_counter()
+    lu = spla.splu(Ap)
+    xs = lu.solve(bp)
+    out["splu_s"] = time.perf_counter() - t0
+    out["splu_cores"] = 1
+    out["oracle_vs_splu_relerr"] = float(np.linalg.norm(x - xs) / np.linalg.norm(xs))
+    del lu
+    # this library on the same sample: one-shot factor from host arrays + ldiv!, and the resident-input step
+    if dev is not None:
+        import torch
+
+        from hierarchicalsolvers_jl_amd import dist as hsdist
+
+        Ap2, bp2, nd2, nd_loc2 = _prepare(hs, sample)
+        S = hsdist.StagedSolver(Ap2, nd2, nd_loc2, device=dev, swlevel=0)
+        bd0 = torch.from_numpy(np.ascontiguousarray(bp2)).to(dev)
+        bd = torch.empty_like(bd0)
+        for rep in range(2):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            S.numeric()
+            bd.copy_(bd0)
+            S.solve(bd)
+            torch.cuda.synchronize(dev)
+            tg = time.perf_counter() - t0
+        out["gpu_same_sample_s"] = tg
+        out["gpu_same_sample_relerr_vs_splu"] = float(np.linalg.norm(bd.cpu().numpy() - xs) / np.linalg.norm(xs))
+        out["gpu_speedup_on_sample"] = dt / tg
+        S.backend.L.hs_free(S.backend._h)
+        S.backend._h = None
+    return out
+
+
+def pmc_traffic(workload, launches, round_tag="r02"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS round (tools/pmc_bench.sh; counters cannot be read
+    from inside the timed process).  Refused -- null plus the reason -- when the file is missing or was measured on a different launch count."""
+    pmc = os.path.join(ROOT, "profiles", "%s_%s_gemm_pmc_traffic.json" % (round_tag, workload))
+    if not os.path.exists(pmc):
+        return None, "no PMC pass of this round for this workload under profiles/ (%s)" % os.path.basename(pmc), None
+    with open(pmc) as f:
+        pj = json.load(f)
+    if int(pj.get("launches", -1)) != int(launches):
+        return None, "profiles/%s was measured on %s launches per factorization, this run has %d: stale, not reported" % (os.path.basename(pmc), pj.get("launches"), launches), None
+    src = "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes with --kernel-trace only, FETCH_SIZE x2 for gfx950; %d launches)" % launches
+    return pj["traffic_bytes_per_launch"], None, src
+
+
+def metric_workload(hs, hsdist, dev, name, swlevel, tol, steps):
+    """BASELINE.json's own workload class on one GPU: complex 3-D Helmholtz, fronts of the top levels compressed at `tol`."""
+    import numpy as np
+    import torch
+
+    Ap, bp, nd, nd_loc = _prepare(hs, name)
+    fopts = dict(swlevel=swlevel, swsize=8, atol=tol, rtol=tol)
+    S = hsdist.StagedSolver(Ap, nd, nd_loc, device=dev, **fopts)
+    bd0 = torch.from_numpy(np.ascontiguousarray(bp)).to(dev)
+    bd = torch.empty_like(bd0)
+
+    def step():
+        S.numeric()
+        bd.copy_(bd0)
+        S.solve(bd)
+
+    step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    per = (time.perf_counter() - t0) / steps
+    st = S.stats()
+    x = bd.cpu().numpy()
+    out = {
+        "workload": name, "n": int(Ap.shape[0]), "dtype": "c128" if np.iscomplexobj(Ap.data) else "f64",
+        "compression": f"swlevel={swlevel} swsize=8 atol=rtol={tol:g}", "steps": steps, "value": per, "unit": "s",
+        "factor_s": st["t_total"], "residual_plain_ldiv": float(np.linalg.norm(Ap @ x - bp) / np.linalg.norm(bp)),
+        "maxrank": int(S.backend.L.hs_maxrank(S.backend._h)), "bytes_factors_GiB": st["bytes_factors"] / 2**30,
+        "dense_flops_minimal_count": st["flops_factor"],
+    }
+    # the scenario's acceptance number: right-preconditioned GMRES(30) to 1e-8 with this factorization (test/rungmres.jl:47-48)
+    try:
+        from hierarchicalsolvers_jl_amd import gmres as hsg
+
+        t0 = time.perf_counter()
+        xg, hist = hsg.gmres_device(Ap, bd0, S, reltol=1e-8, restart=30, maxiter=30)
+        torch.cuda.synchronize(dev)
+        out["gmres"] = {"reltol": 1e-8, "restart": 30, "iterations": len(hist) - 1, "seconds": time.perf_counter() - t0,
+                        "final_relres": float(hist[-1] / hist[0]) if hist[0] > 0 else 0.0}
+    except Exception as e:  # the bench line must not die on the extra
+        out["gmres"] = {"error": repr(e)}
+    S.backend.L.hs_free(S.backend._h)
+    S.backend._h = None
+    return out
 
 
 def main():
@@ -69,6 +185,11 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("HS_BENCH_WORKLOAD", "poisson3d_128"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="poisson3d_32")
+    ap.add_argument("--no-oneshot", action="store_true", help="skip the one-shot factor from host arrays (analysis + numeric)")
+    ap.add_argument("--metric-workload", default="helmholtz3d_112", help="BASELINE.json's workload class measured beside the headline at N = 1 ('' = skip)")
+    ap.add_argument("--metric-swlevel", type=int, default=4)
+    ap.add_argument("--metric-tol", type=float, default=1e-4)
+    ap.add_argument("--metric-steps", type=int, default=2)
     ap.add_argument("--no-profile", action="store_true", help="skip the extra profiled step that feeds `roofline`")
     ap.add_argument("--swlevel", type=int, default=0, help="compress fronts at tree levels <= swlevel (<0: from the leaves); 0 = exact")
     ap.add_argument("--swsize", type=int, default=8)
@@ -194,17 +315,50 @@ def main():
                 "phases_s": {"gemm_updates": sp_["t_gemm"], "panel": sp_["t_panel"], "laswp+trsm": sp_["t_trsm"], "assemble": sp_["t_assemble"],
                              "factor_total_profiled": sp_["t_total"]},
             }
-            # HBM bytes per launch from the committed PMC passes of the same workload (tools/pmc_bench.sh; counters
-            # cannot be read from inside the process)
-            pmc = os.path.join(ROOT, "profiles", "r01_%s_gemm_pmc_traffic.json" % args.workload)
-            if world == 1 and args.swlevel == 0 and os.path.exists(pmc):
-                with open(pmc) as f:
-                    pj = json.load(f)
-                roofline["traffic"] = pj["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 for gfx950)"
+            # HBM bytes per launch: algorithmic (A and B read once, C read and written once, summed over the launches) and measured
+            # (committed PMC passes of this round, refused when their launch count is not this run's)
+            roofline["algorithmic_bytes_per_launch"] = sp_["gemm_bytes"] / max(n_k, 1)
+            roofline["flop_per_algorithmic_byte"] = sp_["gemm_flops"] / max(sp_["gemm_bytes"], 1.0)
+            if world == 1 and args.swlevel == 0:
+                tr, why, src = pmc_traffic(args.workload, n_k)
+                roofline["traffic"] = tr
+                if tr is None:
+                    roofline["traffic_note"] = why
+                else:
+                    roofline["traffic_source"] = src
+                    roofline["traffic_over_algorithmic"] = tr / max(roofline["algorithmic_bytes_per_launch"], 1.0)
+            else:
+                roofline["traffic_note"] = "PMC passes are collected for the single-GPU exact run only"
             peak_meas = S.backend.L.hsk_mfma_f64_peak(2, 100000)
             roofline["peak_measured_issue_rate"] = peak_meas
             roofline["frac_of_measured"] = ach / peak_meas if peak_meas > 0 else None
+
+    maxrank_main = int(S.backend.L.hs_maxrank(S.backend._h)) if getattr(S.backend, "_h", None) else None
+    oneshot = None
+    extra_metric = None
+    if world == 1:
+        # release the resident factorization (139 GiB at 128^3) before anything else allocates
+        S.backend.L.hs_free(S.backend._h)
+        S.backend._h = None
+        del S
+        torch.cuda.empty_cache()
+        if not args.no_oneshot:
+            # what the Julia shim binds: factor(A, nd, nd_loc) from HOST arrays = analysis + arena allocation + upload + numeric, then ldiv!
+            # from a host vector (PCIe-inclusive; never `value`)
+            t0 = time.perf_counter()
+            F1 = hs.factor(Ap, nd, nd_loc, **fopts)
+            t_f1 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            x1 = hs.ldiv(F1, bp)
+            t_l1 = time.perf_counter() - t0
+            oneshot = {"factor_oneshot_s": t_f1, "ldiv_host_s": t_l1, "residual": float(np.linalg.norm(Ap @ x1 - bp) / np.linalg.norm(bp))}
+            F1.free()
+            del F1
+        if args.metric_workload and args.swlevel == 0 and args.workload != args.metric_workload:
+            try:
+                extra_metric = metric_workload(hs, hsdist, dev, args.metric_workload, args.metric_swlevel, args.metric_tol, args.metric_steps)
+            except Exception as e:  # never lose the headline line to the extra
+                extra_metric = {"workload": args.metric_workload, "error": repr(e)}
 
     if rank == 0:
         flops = st["flops_factor"] if world == 1 else None
@@ -227,7 +381,7 @@ def main():
                        "partition": f"subtree-per-rank x{world}"},
             "factor_s": st["t_total"],
             "residual": res,
-            "maxrank": int(S.backend.L.hs_maxrank(S.backend._h)) if getattr(S.backend, "_h", None) else None,
+            "maxrank": maxrank_main,
             "host_symbolic_s": t_host,
             "analyze_s": t_analyze,
         }
@@ -241,8 +395,13 @@ def main():
         if roofline:
             out["roofline"] = roofline
             out["mfma_util_pct"] = 100.0 * roofline["frac"]  # BASELINE.json's metric pairs the time with the MFMA utilisation (FP64-matrix peak 78.6 TF)
+        if oneshot:
+            out["factor_oneshot_s"] = oneshot["factor_oneshot_s"]  # analysis + numeric from host arrays (hs_factor_*), excluded from `value`
+            out["oneshot"] = oneshot
+        if extra_metric:
+            out["metric_workload"] = extra_metric
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(st["flops_factor"], args.cpu_sample, is_c)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, dev)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -42,8 +42,17 @@ class hs_stats(C.Structure):
         ("t_symbolic", C.c_double), ("t_upload", C.c_double), ("t_assemble", C.c_double), ("t_panel", C.c_double),
         ("t_trsm", C.c_double), ("t_gemm", C.c_double), ("t_total", C.c_double), ("t_solve", C.c_double),
         ("gemm_flops", C.c_double), ("gemm_launches", i64),
-        ("t_mfma_kernel", C.c_double), ("mfma_kernel_launches", i64),
+        ("t_mfma_kernel", C.c_double), ("mfma_kernel_launches", i64), ("gemm_bytes", C.c_double),
     ]
+
+
+class hs_sparse_dev(C.Structure):
+    _fields_ = [("n", i64), ("colptr", C.c_void_p), ("rowval", C.c_void_p), ("nzval", C.c_void_p),
+                ("rowptr", C.c_void_p), ("colind", C.c_void_p), ("nzval_r", C.c_void_p)]
+
+
+class hs_hss_blockop(C.Structure):
+    _fields_ = [("n1", i64), ("n2", i64), ("H1", C.c_void_p), ("H2", C.c_void_p), ("gid", p_i64), ("A", C.POINTER(hs_sparse_dev)), ("lpos", C.c_void_p)]
 
 
 class hs_hss_options(C.Structure):
@@ -67,6 +76,7 @@ EXPORTS = [
     "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free", "hs_node_schur_hss",
+    "hs_hss_offdiag", "hs_hss_compress_blockop_d", "hs_hss_compress_blockop_z", "hs_hss_blockop_apply",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_bisect_perm",
 ]
 
@@ -218,6 +228,13 @@ def lib():
     L.hs_hss_mul_t.restype = C.c_int
     L.hs_hss_child.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.hs_hss_child.restype = C.c_int
+    L.hs_hss_offdiag.argtypes = [vp, C.c_int, vp, i64, vp, i64, C.c_int]
+    L.hs_hss_offdiag.restype = C.c_int
+    for f in (L.hs_hss_compress_blockop_d, L.hs_hss_compress_blockop_z):
+        f.argtypes = [C.POINTER(hs_hss_blockop), vp, i64, vp, i64, vp, i64, i64, i64, p_i64, C.POINTER(hs_hss_options), vp, C.POINTER(vp)]
+        f.restype = C.c_int
+    L.hs_hss_blockop_apply.argtypes = [C.POINTER(hs_hss_blockop), C.c_int, vp, i64, vp, i64, i64, C.c_int, vp]
+    L.hs_hss_blockop_apply.restype = C.c_int
     L.hs_hss_factor.argtypes = [vp]
     L.hs_hss_factor.restype = C.c_int
     L.hs_hss_ldiv.argtypes = [vp, vp, i64, i64, C.c_int]

@@ -949,6 +949,7 @@ static void numeric_end(hs_handle* h) {
   h->stats.t_assemble = prof.ms[HS_CAT_ASSEMBLE] * 1e-3;
   h->stats.gemm_flops = prof.flops[HS_CAT_GEMM];
   h->stats.gemm_launches = prof.launches[HS_CAT_GEMM];
+  h->stats.gemm_bytes = prof.gemm_bytes;
   std::vector<int> info(h->nnodes);
   HS_HIP(hipMemcpy(info.data(), h->d_info, h->nnodes * sizeof(int), hipMemcpyDeviceToHost));
   for (int i = 0; i < h->nnodes; ++i)

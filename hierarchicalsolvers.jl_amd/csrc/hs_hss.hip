@@ -90,6 +90,8 @@ struct SubJob {
   int r0, c0, rows, cols;
   T* out;
   int ldo, trans;  // trans: the result is written transposed (out is cols x rows)
+  const int* hri = nullptr;  // HOST copies of ri / ci (+ r0 / c0 already added: absolute indices), for operators that route the
+  const int* hci = nullptr;  // request on the host (BlockOp::gather); null: the range r0 + i
 };
 template <class T>
 __global__ __launch_bounds__(64) void sub_gather_kernel(const SubJob<T>* __restrict__ jobs) {
@@ -254,6 +256,7 @@ struct HNode {
   NodeDesc<T> fd;
   int off_in_parent = 0;  // row offset of this node's skeleton inside the parent's local vectors
   std::vector<int> hinvp;  // host: inverse of p (entry access, filled on first use)
+  std::vector<int> hsk;    // host copy of sk (kept by the matrix-free compression, which routes entry requests on the host)
   T* NTm = nullptr;        // -T (entry access)
   T *DTt = nullptr, *B12t = nullptr, *B21t = nullptr;  // D^T, B12^T (rr x rl), B21^T (rl x rr): transposed product, made on first use
 };
@@ -270,6 +273,7 @@ struct HssT {
   bool own_stream = false;
   int* perm = nullptr;  // device, n entries (0-based) or null: H ~= A[perm, perm]
   std::vector<int> hinvperm;  // host: position of every caller index in the tree's order (empty: identity)
+  std::vector<int> hperm;     // host copy of perm (empty: identity)
   Pool permpool;
   bool factored = false;
   NodeDesc<T> rootfd;  // LU of the last block
@@ -399,7 +403,9 @@ struct Lru {
 // compression with k samples per side; returns false when some rank came too close to k (caller doubles k)
 // ------------------------------------------------------------------------------------------------
 template <class T>
-bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = Lru<T>()) {
+struct BlockOp;  // hs_hss_op.h: [H1 A12; A21 H2] of two HSS blocks and sparse couplings, never formed
+template <class T>
+bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = Lru<T>(), BlockOp<T>* bop = nullptr) {
   const int n = H.n;
   hipStream_t s = H.s;
   Pool tmp(&H.cache);  // samples and everything else that dies with this attempt
@@ -420,7 +426,12 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
   // blocks of A by index lists (the jobs in `subs` all read A): B's entries, minus the low-rank update's
   auto gather_A = [&]() {
     std::vector<SubJob<T>> jobs = subs;
-    run_subs(tmp, subs, s);
+    if (bop) {
+      bop->gather(tmp, subs, s);
+      subs.clear();
+    } else {
+      run_subs(tmp, subs, s);
+    }
     if (!lru.on()) return;
     std::vector<SubJob<T>> pieces;
     std::vector<GemmProb<T>> g1, g2;
@@ -456,7 +467,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     x.m = n;
     x.ldd = ev(n);
     x.D = H.keep.template get<T>((size_t)x.ldd * n);
-    subs.push_back(SubJob<T>{A, lda, H.perm, H.perm, 0, 0, n, n, x.D, x.ldd, 0});
+    subs.push_back(SubJob<T>{A, lda, H.perm, H.perm, 0, 0, n, n, x.D, x.ldd, 0, H.hperm.empty() ? nullptr : H.hperm.data(), H.hperm.empty() ? nullptr : H.hperm.data()});
     gather_A();
     HSS_HIP(hipStreamSynchronize(s));
     return true;
@@ -477,9 +488,17 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
   }
   subs.push_back(SubJob<T>{OPs + (size_t)ldn * k, ldn, nullptr, nullptr, 0, 0, n, k, PsT, ldk, 1});
   run_subs(tmp, subs, s);
-  gemms.push_back(GemmProb<T>{A, OPs, Ys, n, k, n, lda, ldn, ldn});
-  gemms.push_back(GemmProb<T>{PsT, A, W, k, n, n, ldk, lda, ldk});
-  run_gemms(tmp, gemms, 0, s);
+  if (bop) {  // products with the operator and its transpose: Ys[:, :k] = Op*Omega', W = (Op^T*Psi')^T
+    T* Y2 = tmp.get<T>((size_t)ldn * k);
+    bop->mul(OPs, ldn, Ys, ldn, k, false, s);
+    bop->mul(OPs + (size_t)ldn * k, ldn, Y2, ldn, k, true, s);
+    subs.push_back(SubJob<T>{Y2, ldn, nullptr, nullptr, 0, 0, n, k, W, ldk, 1});
+    run_subs(tmp, subs, s);
+  } else {
+    gemms.push_back(GemmProb<T>{A, OPs, Ys, n, k, n, lda, ldn, ldn});
+    gemms.push_back(GemmProb<T>{PsT, A, W, k, n, n, ldk, lda, ldk});
+    run_gemms(tmp, gemms, 0, s);
+  }
   if (lru.on()) {  // Ys -= C*(M*(Z*OPs)),  W -= ((PsT*C)*M)*Z
     const int r1 = lru.r1, r2 = lru.r2;
     T* t1 = tmp.get<T>((size_t)ev(r2) * k);
@@ -534,8 +553,9 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
         DT[i] = tmp.get<T>((size_t)x.ldd * m);
         const int* pl = H.perm ? H.perm + x.lo : nullptr;  // rows / columns of A behind the leaf's positions
         const int o0 = H.perm ? 0 : x.lo;
-        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, x.D, x.ldd, 0});
-        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, DT[i], x.ldd, 1});
+        const int* hpl = H.hperm.empty() ? nullptr : H.hperm.data() + x.lo;
+        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, x.D, x.ldd, 0, hpl, hpl});
+        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, DT[i], x.ldd, 1, hpl, hpl});
         gemms.push_back(GemmProb<T>{x.D, Ol[i], Yl[i], m, k, m, x.ldd, ldl[i], ldl[i]});
         gemms.push_back(GemmProb<T>{DT[i], Ol[i] + (size_t)ldl[i] * k, Yl[i] + (size_t)ldl[i] * k, m, k, m, x.ldd, ldl[i], ldl[i]});
       } else {
@@ -547,10 +567,10 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
         x.B21 = H.keep.template get<T>((size_t)x.ld21 * rl);
         B12T[i] = tmp.get<T>((size_t)x.ld21 * rl);  // rr x rl
         B21T[i] = tmp.get<T>((size_t)x.ld12 * rr);  // rl x rr
-        subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, rl, rr, x.B12, x.ld12, 0});
-        subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, rr, rl, x.B21, x.ld21, 0});
-        subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, rl, rr, B12T[i], x.ld21, 1});
-        subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, rr, rl, B21T[i], x.ld12, 1});
+        subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, rl, rr, x.B12, x.ld12, 0, l.hsk.data(), r.hsk.data()});
+        subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, rr, rl, x.B21, x.ld21, 0, r.hsk.data(), l.hsk.data()});
+        subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, rl, rr, B12T[i], x.ld21, 1, l.hsk.data(), r.hsk.data()});
+        subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, rr, rl, B21T[i], x.ld12, 1, r.hsk.data(), l.hsk.data()});
         T *Yi = Yl[i], *Oi = Ol[i];
         const size_t ck = (size_t)ld * k;
         gemms.push_back(GemmProb<T>{x.B12, Oi + rl, Yi, rl, k, rr, x.ld12, ld, ld});              // Sr_l -= B12 * Om~_r
@@ -693,6 +713,13 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       }
       IdxJob* dij = upload(tmp, ij);
       hipLaunchKernelGGL(idx_compose_kernel, dim3((maxr + 63) / 64, (unsigned)ij.size()), dim3(64), 0, s, (const IdxJob*)dij);
+      if (bop) {  // the matrix-free operator routes entry requests on the host: it needs the skeleton indices there
+        for (int i : L) {
+          nd[i].hsk.resize((size_t)nd[i].r);
+          HSS_HIP(hipMemcpyAsync(nd[i].hsk.data(), nd[i].sk, sizeof(int) * (size_t)nd[i].r, hipMemcpyDeviceToHost, s));
+        }
+        HSS_HIP(hipStreamSynchronize(s));
+      }
       // ---- d. hand the skeleton rows of the samples and the compressed test matrices to the parents ------------------------
       if (lv > 1) {
         std::vector<T*> GR(N, nullptr);
@@ -744,8 +771,8 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     x.ld21 = ev(r.r);
     x.B12 = H.keep.template get<T>((size_t)x.ld12 * r.r);
     x.B21 = H.keep.template get<T>((size_t)x.ld21 * l.r);
-    subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, l.r, r.r, x.B12, x.ld12, 0});
-    subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, r.r, l.r, x.B21, x.ld21, 0});
+    subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, l.r, r.r, x.B12, x.ld12, 0, l.hsk.data(), r.hsk.data()});
+    subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, r.r, l.r, x.B21, x.ld21, 0, r.hsk.data(), l.hsk.data()});
     gather_A();
   }
   HSS_HIP(hipStreamSynchronize(s));
@@ -877,192 +904,35 @@ void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q, bool trans
   HSS_HIP(hipStreamSynchronize(s));
 }
 
+#include "hs_hss_op.h"
+
 // ------------------------------------------------------------------------------------------------
 // entries: out = H[I, J] for index lists (the `getindex` an operator assembled from HSS blocks is asked for,
 // src/factorization.jl:129-137,246-249).  O((|I| + |J|) * r) per tree level: the basis rows of the requested
 // indices are carried up the tree -- as rows E (I side) and as columns F = E^T (J side) -- and every inner node
 // contributes E_l * B12 * F_r and E_r * B21 * F_l to the block of its two index ranges; leaves contribute D[I, J].
+// One pair here; hss_getindex_batch (hs_hss_op.h) serves many pairs with one group of launches per tree level.
 // ------------------------------------------------------------------------------------------------
 template <class T>
 void hss_getindex(HssT<T>& H, const int64_t* I, int ni, const int64_t* J, int nj, T* out, int ldo) {
-  hipStream_t s = H.s;
-  auto& nd = H.nd;
-  const int N = (int)nd.size();
-  Pool tmp(&H.cache);
   if (ni <= 0 || nj <= 0) return;
-  // positions in the tree's order, sorted (the subsets of a node are contiguous then)
-  auto prep = [&](const int64_t* X, int cnt, std::vector<int>& pos, std::vector<int>& ord) {
-    pos.resize(cnt);
-    ord.resize(cnt);
-    for (int a = 0; a < cnt; ++a) {
-      if (X[a] < 0 || X[a] >= H.n) {
-        hs_set_error(HS_ERR_ARGUMENT, a, "BoundsError: index %lld outside 0:%d", (long long)X[a], H.n - 1);
-        throw (int)HS_ERR_ARGUMENT;
-      }
-      pos[a] = H.hinvperm.empty() ? (int)X[a] : H.hinvperm[(size_t)X[a]];
-      ord[a] = a;
+  std::vector<int> hi((size_t)ni), hj((size_t)nj);
+  for (int a = 0; a < ni; ++a) {
+    if (I[a] < 0 || I[a] >= H.n) {
+      hs_set_error(HS_ERR_ARGUMENT, a, "BoundsError: index %lld outside 0:%d", (long long)I[a], H.n - 1);
+      throw (int)HS_ERR_ARGUMENT;
     }
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return pos[a] < pos[b]; });
-  };
-  std::vector<int> pI, oI, pJ, oJ;
-  prep(I, ni, pI, oI);
-  prep(J, nj, pJ, oJ);
-  std::vector<int> sI(ni), sJ(nj);  // sorted positions
-  for (int a = 0; a < ni; ++a) sI[a] = pI[oI[a]];
-  for (int a = 0; a < nj; ++a) sJ[a] = pJ[oJ[a]];
-  auto range = [](const std::vector<int>& v, int lo, int hi, int& b, int& e) {
-    b = (int)(std::lower_bound(v.begin(), v.end(), lo) - v.begin());
-    e = (int)(std::lower_bound(v.begin(), v.end(), hi) - v.begin());
-  };
-  const int ldS = ev(ni);
-  T* outS = tmp.get<T>((size_t)ldS * nj);  // result in sorted order
-  HSS_HIP(hipMemsetAsync(outS, 0, sizeof(T) * (size_t)ldS * nj, s));
-  std::vector<int> bI(N), eI(N), bJ(N), eJ(N);
-  for (int i = 0; i < N; ++i) {
-    range(sI, nd[i].lo, nd[i].hi, bI[i], eI[i]);
-    range(sJ, nd[i].lo, nd[i].hi, bJ[i], eJ[i]);
+    hi[(size_t)a] = (int)I[a];
   }
-  std::vector<SubJob<T>> subs;
-  std::vector<RowJob<T>> rows;
-  std::vector<GemmProb<T>> gemms, g2;
-  std::vector<BasisJob<T>> bjobs;
-  std::vector<T*> E(N, nullptr), F(N, nullptr);  // E: cntI x r (ld ev(cntI)); F: r x cntJ (ld ev(r))
-  int maxcnt = 0, maxr = 0;
-  // leaves: diagonal blocks and basis rows
-  for (int i = 0; i < N; ++i) {
-    HNode<T>& x = nd[i];
-    if (x.left >= 0) continue;
-    const int cI = eI[i] - bI[i], cJ = eJ[i] - bJ[i];
-    if (cI == 0 && cJ == 0) continue;
-    std::vector<int> li(cI), lj(cJ);
-    for (int a = 0; a < cI; ++a) li[a] = sI[bI[i] + a] - x.lo;
-    for (int a = 0; a < cJ; ++a) lj[a] = sJ[bJ[i] + a] - x.lo;
-    if (cI > 0 && cJ > 0) {
-      int* dli = upload(tmp, li);
-      int* dlj = upload(tmp, lj);
-      subs.push_back(SubJob<T>{x.D, x.ldd, dli, dlj, 0, 0, cI, cJ, outS + bI[i] + (size_t)ldS * bJ[i], ldS, 0});
+  for (int a = 0; a < nj; ++a) {
+    if (J[a] < 0 || J[a] >= H.n) {
+      hs_set_error(HS_ERR_ARGUMENT, a, "BoundsError: index %lld outside 0:%d", (long long)J[a], H.n - 1);
+      throw (int)HS_ERR_ARGUMENT;
     }
-    if (i == 0) continue;
-    if (x.hinvp.empty()) {
-      std::vector<int> hp(x.m);
-      HSS_HIP(hipMemcpy(hp.data(), x.p, sizeof(int) * x.m, hipMemcpyDeviceToHost));
-      x.hinvp.assign(x.m, 0);
-      for (int a = 0; a < x.m; ++a) x.hinvp[hp[a]] = a;
-    }
-    for (int side = 0; side < 2; ++side) {
-      const std::vector<int>& l = side == 0 ? li : lj;
-      const int cnt = (int)l.size();
-      if (cnt == 0) continue;
-      std::vector<int> ip(cnt);
-      for (int a = 0; a < cnt; ++a) ip[a] = x.hinvp[l[a]];
-      int* dip = upload(tmp, ip);
-      T* o = side == 0 ? (E[i] = tmp.get<T>((size_t)ev(cnt) * x.r)) : (F[i] = tmp.get<T>((size_t)ev(x.r) * cnt));
-      bjobs.push_back(BasisJob<T>{x.Tm, x.ldt, x.r, cnt, dip, o, side == 0 ? ev(cnt) : ev(x.r), side});
-      maxcnt = std::max(maxcnt, cnt);
-      maxr = std::max(maxr, x.r);
-    }
+    hj[(size_t)a] = (int)J[a];
   }
-  run_subs(tmp, subs, s);
-  if (!bjobs.empty()) {
-    BasisJob<T>* dj = upload(tmp, bjobs);
-    hipLaunchKernelGGL(basis_rows_kernel<T>, dim3((maxcnt + 63) / 64, (maxr + 15) / 16, (unsigned)bjobs.size()), dim3(64), 0, s, (const BasisJob<T>*)dj);
-  }
-  // inner nodes, deepest level first: couplings of the two children, then the node's own basis rows for its parent
-  for (int lv = H.nlev - 2; lv >= 0; --lv) {
-    std::vector<GemmProb<T>> ga, gb;
-    std::vector<RowJob<T>> rj;
-    for (int i : H.lev[lv]) {
-      HNode<T>& x = nd[i];
-      if (x.left < 0) continue;
-      const int l = x.left, r = x.right, rl = nd[l].r, rr = nd[r].r;
-      const int cIl = eI[l] - bI[l], cIr = eI[r] - bI[r], cJl = eJ[l] - bJ[l], cJr = eJ[r] - bJ[r];
-      // out[I_l, J_r] = E_l * B12 * F_r,  out[I_r, J_l] = E_r * B21 * F_l
-      if (cIl > 0 && cJr > 0 && rl > 0 && rr > 0) {
-        T* t = tmp.get<T>((size_t)ev(cIl) * rr);
-        HSS_HIP(hipMemsetAsync(t, 0, sizeof(T) * (size_t)ev(cIl) * rr, s));
-        ga.push_back(GemmProb<T>{E[l], x.B12, t, cIl, rr, rl, ev(cIl), x.ld12, ev(cIl)});
-        gb.push_back(GemmProb<T>{t, F[r], outS + bI[l] + (size_t)ldS * bJ[r], cIl, cJr, rr, ev(cIl), ev(rr), ldS});
-      }
-      if (cIr > 0 && cJl > 0 && rl > 0 && rr > 0) {
-        T* t = tmp.get<T>((size_t)ev(cIr) * rl);
-        HSS_HIP(hipMemsetAsync(t, 0, sizeof(T) * (size_t)ev(cIr) * rl, s));
-        ga.push_back(GemmProb<T>{E[r], x.B21, t, cIr, rl, rr, ev(cIr), x.ld21, ev(cIr)});
-        gb.push_back(GemmProb<T>{t, F[l], outS + bI[r] + (size_t)ldS * bJ[l], cIr, cJl, rl, ev(cIr), ev(rl), ldS});
-      }
-      if (i == 0) continue;
-      // the node's own rows: W = [E_l 0; 0 E_r] -> E = W[:, p_S] + W[:, p_R] * T;   Wt = [F_l 0; 0 F_r] -> F = Wt[p_S, :] + T^T * Wt[p_R, :]
-      const int m = x.m, rk = x.r, nR = m - rk;
-      if (!x.NTm && nR > 0) {
-        x.NTm = H.keep.template get<T>((size_t)x.ldt * rk);
-        rows.push_back(RowJob<T>{x.Tm, x.ldt, x.NTm, x.ldt, nullptr, nR, rk, ROW_GATHER_NEG});
-      }
-      const int cI = cIl + cIr, cJ = cJl + cJr;
-      if (cI > 0) {
-        const int ldw = ev(cI);
-        T* W = tmp.get<T>((size_t)ldw * m);
-        HSS_HIP(hipMemsetAsync(W, 0, sizeof(T) * (size_t)ldw * m, s));
-        if (cIl > 0) subs.push_back(SubJob<T>{E[l], ev(cIl), nullptr, nullptr, 0, 0, cIl, rl, W, ldw, 0});
-        if (cIr > 0) subs.push_back(SubJob<T>{E[r], ev(cIr), nullptr, nullptr, 0, 0, cIr, rr, W + cIl + (size_t)ldw * rl, ldw, 0});
-        E[i] = tmp.get<T>((size_t)ldw * rk);
-        T* Wr = nR > 0 ? tmp.get<T>((size_t)ldw * nR) : nullptr;
-        // column gathers by p: queued behind the block copies (second batch below)
-        g2.push_back(GemmProb<T>{W, nullptr, E[i], cI, rk, 0, ldw, 0, ldw});  // placeholder carrying W / E (see below)
-        g2.back().B = (const T*)Wr;
-        g2.back().K = nR;
-      }
-      if (cJ > 0) {
-        const int ldw = ev(m);
-        T* Wt = tmp.get<T>((size_t)ldw * cJ);
-        HSS_HIP(hipMemsetAsync(Wt, 0, sizeof(T) * (size_t)ldw * cJ, s));
-        if (cJl > 0) subs.push_back(SubJob<T>{F[l], ev(rl), nullptr, nullptr, 0, 0, rl, cJl, Wt, ldw, 0});
-        if (cJr > 0) subs.push_back(SubJob<T>{F[r], ev(rr), nullptr, nullptr, 0, 0, rr, cJr, Wt + rl + (size_t)ldw * cJl, ldw, 0});
-        F[i] = tmp.get<T>((size_t)ev(rk) * cJ);
-        rj.push_back(RowJob<T>{Wt, ldw, F[i], ev(rk), x.p, rk, cJ, ROW_GATHER});
-        if (nR > 0) {
-          T* t = tmp.get<T>((size_t)ev(nR) * cJ);
-          rj.push_back(RowJob<T>{Wt, ldw, t, ev(nR), x.p + rk, nR, cJ, ROW_GATHER_NEG});
-          gemms.push_back(GemmProb<T>{x.Tt, t, F[i], rk, cJ, nR, x.ldtt, ev(nR), ev(rk)});  // F += T^T * Wt[p_R, :]
-        }
-      }
-    }
-    run_rows(tmp, rows, s);   // -T copies
-    run_gemms(tmp, ga, 0, s);
-    run_gemms(tmp, gb, 0, s);
-    run_subs(tmp, subs, s);   // W, Wt blocks
-    // E side: column gathers W[:, p_S] -> E, W[:, p_R] -> Wr, then E -= Wr * (-T)
-    std::vector<SubJob<T>> cg;
-    std::vector<GemmProb<T>> ge;
-    {
-      size_t gi = 0;
-      for (int i : H.lev[lv]) {
-        HNode<T>& x = nd[i];
-        if (x.left < 0 || i == 0) continue;
-        const int cI = (eI[x.left] - bI[x.left]) + (eI[x.right] - bI[x.right]);
-        if (cI <= 0) continue;
-        const GemmProb<T>& ph = g2[gi++];
-        const int ldw = ev(cI), rk = x.r, nR = x.m - rk;
-        cg.push_back(SubJob<T>{ph.A, ldw, nullptr, x.p, 0, 0, cI, rk, ph.C, ldw, 0});
-        if (nR > 0) {
-          cg.push_back(SubJob<T>{ph.A, ldw, nullptr, x.p + rk, 0, 0, cI, nR, (T*)ph.B, ldw, 0});
-          ge.push_back(GemmProb<T>{ph.B, x.NTm, ph.C, cI, rk, nR, ldw, x.ldt, ldw});
-        }
-      }
-      g2.clear();
-    }
-    run_subs(tmp, cg, s);
-    run_gemms(tmp, ge, 1, s);
-    run_rows(tmp, rj, s);
-    run_gemms(tmp, gemms, 1, s);
-  }
-  // back to the caller's order
-  std::vector<int> rI(ni), rJ(nj);
-  for (int a = 0; a < ni; ++a) rI[oI[a]] = a;
-  for (int a = 0; a < nj; ++a) rJ[oJ[a]] = a;
-  int* drI = upload(tmp, rI);
-  int* drJ = upload(tmp, rJ);
-  subs.push_back(SubJob<T>{outS, ldS, drI, drJ, 0, 0, ni, nj, out, ldo, 0});
-  run_subs(tmp, subs, s);
-  HSS_HIP(hipStreamSynchronize(s));
+  std::vector<GiJob<T>> one{GiJob<T>{hi.data(), ni, hj.data(), nj, out, ldo}};
+  hss_getindex_batch<T>(H, one);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1423,13 +1293,13 @@ struct LruArgs {  // host-side description of the optional update  - C*M*Z  (poi
 };
 template <class T>
 HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_hss_options* o, const int64_t* perm = nullptr, void* stream = nullptr,
-                       const LruArgs* la = nullptr) {
+                       const LruArgs* la = nullptr, BlockOp<T>* bop = nullptr) {
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
     hs_set_error(HS_ERR_DEVICE, 0, "no HIP device available (the HSS module has no CPU fallback)");
     throw (int)HS_ERR_DEVICE;
   }
-  if (n <= 0 || n > (1 << 30) || lda < n || !A) {
+  if (n <= 0 || n > (1 << 30) || (!bop && (lda < n || !A))) {
     hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_compress needs n > 0, lda >= n and a matrix");
     throw (int)HS_ERR_ARGUMENT;
   }
@@ -1464,13 +1334,14 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
     }
     H->hinvperm.assign((size_t)n, 0);
     for (int64_t i = 0; i < n; ++i) H->hinvperm[(size_t)hp[(size_t)i]] = (int)i;
+    H->hperm = hp;
     H->perm = H->permpool.template get<int>((size_t)n);
     HSS_HIP(hipMemcpy(H->perm, hp.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
   }
   Pool in;
   const T* dA = A;
   int ld = (int)lda;
-  if (where == 0) {
+  if (where == 0 && !bop) {
     ld = ev((int)n);
     T* d = in.get<T>((size_t)ld * n);
     HSS_HIP(hipMemcpy2D(d, sizeof(T) * ld, A, sizeof(T) * lda, sizeof(T) * n, n, hipMemcpyHostToDevice));
@@ -1502,11 +1373,18 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
   }
   auto t0 = std::chrono::steady_clock::now();
   int k = (int)std::min<int64_t>(std::max<int64_t>(opt.kest > 0 ? opt.kest : 64, 8), n);
-  for (;;) {
-    if (compress_fixed<T>(*H, dA, ld, k, lru)) break;
-    if (k >= n) break;
-    k = (int)std::min<int64_t>(2 * (int64_t)k, n);
+  if (bop) bop->begin(H->s);
+  try {
+    for (;;) {
+      if (compress_fixed<T>(*H, dA, ld, k, lru, bop)) break;
+      if (k >= n) break;
+      k = (int)std::min<int64_t>(2 * (int64_t)k, n);
+    }
+  } catch (...) {
+    if (bop) bop->end(H->s);
+    throw;
   }
+  if (bop) bop->end(H->s);
   H->t_compress = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return H.release();
 }
@@ -1696,11 +1574,11 @@ extern "C" int hs_hss_mul_t(hs_hss* H, const double* X, int64_t ldx, double* Y, 
 // generators of H (H must outlive it).  Its index space is the block's own: 0 .. size-1 in the order of the cluster tree.
 template <class T>
 static HssT<T>* child_impl(HssT<T>* P, int which) {
-  if (P->nd[0].left < 0) {
+  if (P->nd[0].left < 0 && which != 2) {
     hs_set_error(HS_ERR_HSS_LEAF, 0, "One of the Schur complements turned into a leaf. Aborting.");  // factorization.jl:164
     throw (int)HS_ERR_HSS_LEAF;
   }
-  const int top = which == 0 ? P->nd[0].left : P->nd[0].right;
+  const int top = which == 2 ? 0 : (which == 0 ? P->nd[0].left : P->nd[0].right);
   const int off = P->nd[top].lo;
   std::vector<int> ids, cur{top};
   while (!cur.empty()) {  // breadth-first renumbering of the subtree
@@ -1726,7 +1604,7 @@ static HssT<T>* child_impl(HssT<T>* P, int which) {
     HNode<T> y = P->nd[old];  // shares every device pointer
     y.lo -= off;
     y.hi -= off;
-    y.level -= 1;
+    if (which != 2) y.level -= 1;
     y.parent = old == top ? -1 : nw[y.parent];
     if (y.left >= 0) {
       y.left = nw[y.left];
@@ -1734,7 +1612,7 @@ static HssT<T>* child_impl(HssT<T>* P, int which) {
     }
     y.has_front = false;
     memset(&y.fd, 0, sizeof y.fd);
-    if (old == top) {  // a root keeps no basis
+    if (old == top && which != 2) {  // a root keeps no basis
       y.p = nullptr; y.sk = nullptr; y.Tm = nullptr; y.Tt = nullptr; y.NTm = nullptr;
       y.m = y.left >= 0 ? P->nd[P->nd[old].left].r + P->nd[P->nd[old].right].r : y.hi - y.lo;
       y.r = 0;
@@ -1749,7 +1627,7 @@ static HssT<T>* child_impl(HssT<T>* P, int which) {
   return C.release();
 }
 extern "C" int hs_hss_child(hs_hss* H, int which, hs_hss** out) {
-  if (!H || !out || (which != 0 && which != 1)) return HS_ERR_ARGUMENT;
+  if (!H || !out || which < 0 || which > 2) return HS_ERR_ARGUMENT;
   *out = nullptr;
   HSS_GUARD(*out = H->is_complex ? new hs_hss{1, child_impl<cplx>(HZ(H), which)} : new hs_hss{0, child_impl<double>(HD(H), which)});
 }
@@ -1810,6 +1688,146 @@ extern "C" int hs_hss_basis(hs_hss* H, int64_t node, double* out, int64_t ldo, i
           HSS_HIP(hipMemcpy2D(out, sizeof(double) * ldo, d, sizeof(double) * ld, sizeof(double) * rows, r, hipMemcpyDeviceToHost));
         }
       });
+}
+
+// The off-diagonal blocks of the top-level split in low-rank form (device or host output):
+//   which = 0:  A12 = C * Z  with C = U_1 * B12 (n1 x r2), Z = U_2^T (r2 x n2)
+//   which = 1:  A21 = C * Z  with C = U_2 * B21 (n2 x r1), Z = U_1^T (r1 x n1)
+// -- `Uint = generators(S.A11)[1] * S.B12`, `Vbnd = generators(S.A22)[2]` of src/factorization.jl:129-132.
+template <class T>
+static void offdiag_impl(HssT<T>& H, int which, T* C_, int ldc, T* Z, int ldz) {
+  if (H.nd[0].left < 0) {
+    hs_set_error(HS_ERR_HSS_LEAF, 0, "One of the Schur complements turned into a leaf. Aborting.");
+    throw (int)HS_ERR_HSS_LEAF;
+  }
+  hipStream_t s = H.s;
+  Pool tmp(&H.cache);
+  const int a = which == 0 ? H.nd[0].left : H.nd[0].right, b = which == 0 ? H.nd[0].right : H.nd[0].left;
+  const int na = H.nd[a].hi - H.nd[a].lo, nb = H.nd[b].hi - H.nd[b].lo, ra = H.nd[a].r, rb = H.nd[b].r;
+  if (ldc < na || ldz < rb) {
+    hs_set_error(HS_ERR_DIMENSION, 0, "DimensionMismatch: hs_hss_offdiag needs ldc >= %d, ldz >= %d", na, rb);
+    throw (int)HS_ERR_DIMENSION;
+  }
+  T* Ua = tmp.get<T>((size_t)ev(na) * std::max(ra, 1));
+  T* Ub = tmp.get<T>((size_t)ev(nb) * std::max(rb, 1));
+  hss_basis<T>(H, a, Ua, ev(na));
+  hss_basis<T>(H, b, Ub, ev(nb));
+  const T* Bc = which == 0 ? H.nd[0].B12 : H.nd[0].B21;
+  const int ldb = which == 0 ? H.nd[0].ld12 : H.nd[0].ld21;
+  HSS_HIP(hipMemset2DAsync(C_, sizeof(T) * ldc, 0, sizeof(T) * na, rb, s));
+  std::vector<GemmProb<T>> g{GemmProb<T>{Ua, Bc, C_, na, rb, ra, ev(na), ldb, ldc}};
+  run_gemms(tmp, g, 0, s);
+  std::vector<SubJob<T>> t{SubJob<T>{Ub, ev(nb), nullptr, nullptr, 0, 0, nb, rb, Z, ldz, 1}};
+  run_subs(tmp, t, s);
+  HSS_HIP(hipStreamSynchronize(s));
+}
+extern "C" int hs_hss_offdiag(hs_hss* H, int which, double* C_, int64_t ldc, double* Z, int64_t ldz, int where) {
+  if (!H || !C_ || !Z || (which != 0 && which != 1)) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_offdiag needs which in {0, 1} and two output blocks");
+    return HS_ERR_ARGUMENT;
+  }
+  HSS_GUARD(
+      int64_t ia[8]; int64_t ib[8];
+      const int64_t l = HSS_DISPATCH(H, HD(H)->nd[0].left, HZ(H)->nd[0].left), r = HSS_DISPATCH(H, HD(H)->nd[0].right, HZ(H)->nd[0].right);
+      if (l < 0) {
+        hs_set_error(HS_ERR_HSS_LEAF, 0, "One of the Schur complements turned into a leaf. Aborting.");
+        throw (int)HS_ERR_HSS_LEAF;
+      }
+      (void)hs_hss_node_info(H, which == 0 ? l : r, ia); (void)hs_hss_node_info(H, which == 0 ? r : l, ib);
+      const int na = (int)(ia[1] - ia[0]), nb = (int)(ib[1] - ib[0]), rb = (int)ib[6];
+      if (where != 0) {
+        if (H->is_complex) offdiag_impl<cplx>(*HZ(H), which, (cplx*)C_, (int)ldc, (cplx*)Z, (int)ldz);
+        else offdiag_impl<double>(*HD(H), which, C_, (int)ldc, Z, (int)ldz);
+      } else {
+        Pool st;
+        const int lc = ev(na), lz = ev(rb);
+        const size_t esz = H->is_complex ? 16 : 8;
+        void* dC = st.get<char>((size_t)lc * std::max(rb, 1) * esz);
+        void* dZ = st.get<char>((size_t)lz * std::max(nb, 1) * esz);
+        if (H->is_complex) offdiag_impl<cplx>(*HZ(H), which, (cplx*)dC, lc, (cplx*)dZ, lz);
+        else offdiag_impl<double>(*HD(H), which, (double*)dC, lc, (double*)dZ, lz);
+        if (rb > 0) {
+          HSS_HIP(hipMemcpy2D(C_, esz * ldc, dC, esz * lc, esz * na, rb, hipMemcpyDeviceToHost));
+          HSS_HIP(hipMemcpy2D(Z, esz * ldz, dZ, esz * lz, esz * rb, nb, hipMemcpyDeviceToHost));
+        }
+      });
+}
+
+// ---- operators made of HSS blocks and sparse couplings (hs_hss_op.h) behind the C ABI --------------------------------------------
+template <class T>
+static void make_blockop(const hs_hss_blockop* d, BlockOp<T>& op) {
+  if (!d || d->n1 < 0 || d->n2 < 0 || d->n1 + d->n2 <= 0 || !d->gid || !d->A || !d->lpos || (d->n1 > 0 && !d->H1) || (d->n2 > 0 && !d->H2)) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: incomplete hs_hss_blockop");
+    throw (int)HS_ERR_ARGUMENT;
+  }
+  op.n1 = (int)d->n1;
+  op.n = (int)(d->n1 + d->n2);
+  auto blk = [&](hs_hss* H, int64_t sz) -> HssT<T>* {
+    if (sz == 0) return nullptr;
+    if ((H->is_complex != 0) != (sizeof(T) == 16) || hs_hss_size(H) != sz) {
+      hs_set_error(HS_ERR_DIMENSION, 0, "DimensionMismatch: diagonal block of the operator has size %lld, expected %lld", (long long)hs_hss_size(H), (long long)sz);
+      throw (int)HS_ERR_DIMENSION;
+    }
+    return (HssT<T>*)H->impl;
+  };
+  op.H1 = blk(d->H1, d->n1);
+  op.H2 = blk(d->H2, d->n2);
+  op.hgid.resize((size_t)op.n);
+  for (int i = 0; i < op.n; ++i) {
+    if (d->gid[i] < 0 || d->gid[i] >= d->A->n) {
+      hs_set_error(HS_ERR_DIMENSION, i, "BoundsError: global id %lld outside 0:%lld", (long long)d->gid[i], (long long)d->A->n - 1);
+      throw (int)HS_ERR_DIMENSION;
+    }
+    op.hgid[(size_t)i] = (int)d->gid[i];
+  }
+  op.lpos = d->lpos;
+  op.A.n = d->A->n;
+  op.A.colptr = d->A->colptr; op.A.rowval = d->A->rowval; op.A.nz = (const T*)d->A->nzval;
+  op.A.rowptr = d->A->rowptr; op.A.colind = d->A->colind; op.A.nzr = (const T*)d->A->nzval_r;
+}
+template <class T>
+static hs_hss* compress_blockop(const hs_hss_blockop* d, const LruArgs& la, const int64_t* perm, const hs_hss_options* o, void* stream) {
+  BlockOp<T> op;
+  make_blockop<T>(d, op);
+  return new hs_hss{sizeof(T) == 16, compress_impl<T>(op.n, nullptr, 0, 1, o, perm, stream, &la, &op)};
+}
+extern "C" int hs_hss_compress_blockop_d(const hs_hss_blockop* op, const double* C_, int64_t ldc, const double* M, int64_t ldm, const double* Z, int64_t ldz,
+                                         int64_t r1, int64_t r2, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out) {
+  if (!out) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  LruArgs la{C_, M, Z, ldc, ldm, ldz, r1, r2};
+  HSS_GUARD(*out = compress_blockop<double>(op, la, perm, o, stream));
+}
+extern "C" int hs_hss_compress_blockop_z(const hs_hss_blockop* op, const double* C_, int64_t ldc, const double* M, int64_t ldm, const double* Z, int64_t ldz,
+                                         int64_t r1, int64_t r2, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out) {
+  if (!out) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  LruArgs la{C_, M, Z, ldc, ldm, ldz, r1, r2};
+  HSS_GUARD(*out = compress_blockop<cplx>(op, la, perm, o, stream));
+}
+// Y = Op * X (trans != 0: Op^T * X) for device blocks of nrhs columns in the operator's index order
+template <class T>
+static void blockop_apply(const hs_hss_blockop* d, const T* X, int ldx, T* Y, int ldy, int q, int trans, hipStream_t s) {
+  BlockOp<T> op;
+  make_blockop<T>(d, op);
+  op.begin(s);
+  try {
+    HSS_HIP(hipMemset2DAsync(Y, sizeof(T) * ldy, 0, sizeof(T) * op.n, q, s));
+    op.mul(X, ldx, Y, ldy, q, trans != 0, s);
+  } catch (...) {
+    op.end(s);
+    throw;
+  }
+  op.end(s);
+}
+extern "C" int hs_hss_blockop_apply(const hs_hss_blockop* op, int is_complex, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int trans, void* stream) {
+  if (!op || !X || !Y || nrhs < 0 || X == Y) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_blockop_apply needs distinct device blocks X and Y");
+    return HS_ERR_ARGUMENT;
+  }
+  if (nrhs == 0) return HS_OK;
+  HSS_GUARD(if (is_complex) blockop_apply<cplx>(op, (const cplx*)X, (int)ldx, (cplx*)Y, (int)ldy, (int)nrhs, trans, (hipStream_t)stream);
+            else blockop_apply<double>(op, X, (int)ldx, Y, (int)ldy, (int)nrhs, trans, (hipStream_t)stream));
 }
 
 extern "C" int hs_hss_factor(hs_hss* H) {

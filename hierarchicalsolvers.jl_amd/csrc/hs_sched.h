@@ -28,6 +28,7 @@ struct Profiler {
   double ms_tag[64][HS_NCAT] = {};
   std::vector<Rec> recs;
   double flops[HS_NCAT] = {0, 0, 0, 0, 0};
+  double gemm_bytes = 0.0;              // algorithmic bytes of the GEMM launches: A + B read once, C read and written once
   double ms[HS_NCAT] = {0, 0, 0, 0, 0};
   long long launches[HS_NCAT] = {0, 0, 0, 0, 0};
   hipEvent_t begin(hipStream_t s) {
@@ -114,7 +115,10 @@ struct Sched {
         int ni = h_ni[i], nb = h_nb[i], m = ni + nb;
         int rows = cmat == HS_MAT_LF ? m : (cmat == HS_MAT_UR ? ni : nb), cols = cmat == HS_MAT_LF ? ni : nb;
         double Mi = std::min(r1, rows) - r0, Ni = std::min(c1, cols) - c0, Ki = std::min(k1, ni) - k0;
-        if (Mi > 0 && Ni > 0 && Ki > 0) fl += 2.0 * Mi * Ni * Ki;
+        if (Mi > 0 && Ni > 0 && Ki > 0) {
+          fl += 2.0 * Mi * Ni * Ki;
+          pf->gemm_bytes += (Mi * Ki + Ki * Ni + 2.0 * Mi * Ni) * sizeof(T);
+        }
       }
       if (sizeof(T) == 16) fl *= 4.0;
     }

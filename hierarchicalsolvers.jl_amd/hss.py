@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["HssMatrix", "compress", "compress_lowrank_update", "randcompress_adaptive", "hssrank", "bisection_cluster"]
+__all__ = ["HssMatrix", "compress", "compress_lowrank_update", "randcompress_adaptive", "hssrank", "bisection_cluster", "SparseDevice", "BlockOperator"]
 
 
 def bisection_cluster(n, leafsize=64):
@@ -140,6 +140,22 @@ class HssMatrix:
         _lib.check(self.L.hs_hss_mul_t(self._h, X2.ctypes.data_as(C.c_void_p), n, Y.ctypes.data_as(C.c_void_p), n, q, 0))
         return Y[:, 0] if one else Y
 
+    def offdiag_lowrank(self, which):
+        """``(C, Z)`` with ``A12 = C @ Z`` (``which = 0``: ``C = U1 @ B12``, ``Z = U2.T``) or ``A21 = C @ Z`` (``which = 1``) for the top-level
+        split: the thin factors a parent front takes ``Aib`` / ``Abi`` from (``Uint = generators(S.A11)[1]*S.B12``, factorization.jl:129-137)."""
+        root = self._info(0)
+        a, b = (root["left"], root["right"]) if which == 0 else (root["right"], root["left"])
+        da, db = self._info(a), self._info(b)
+        na, nb, rb = da["hi"] - da["lo"], db["hi"] - db["lo"], db["r"]
+        Cm = np.zeros((max(rb, 1), na), dtype=self.dtype)  # column-major na x rb
+        Z = np.zeros((nb, max(rb, 1)), dtype=self.dtype)   # column-major rb x nb
+        _lib.check(self.L.hs_hss_offdiag(self._h, int(which), Cm.ctypes.data_as(C.c_void_p), na, Z.ctypes.data_as(C.c_void_p), max(rb, 1), 0))
+        return Cm.T[:, :rb].copy(), Z.T[:rb].copy()
+
+    def view(self):
+        """All of ``H`` as a view in cluster-tree order (``H``'s own permutation dropped); shares the generators."""
+        return self.block(2)
+
     def block(self, which):
         """``H.A11`` (0) or ``H.A22`` (1): the diagonal block of the top-level split as an HSS matrix sharing this one's generators."""
         h = C.c_void_p()
@@ -222,3 +238,89 @@ def randcompress_adaptive(A, cl=None, *, kest=64, **kw):
 
 def hssrank(H):
     return H.rank
+
+
+class SparseDevice:
+    """A sparse matrix resident on the GPU as CSC and CSR (0-based), plus the scratch map the block operators use (``hs_sparse_dev``)."""
+
+    def __init__(self, A, device="cuda:0"):
+        import scipy.sparse as sp
+        import torch
+
+        A = sp.csc_matrix(A)
+        A.sort_indices()
+        R = sp.csr_matrix(A)
+        R.sort_indices()
+        self.is_complex = bool(np.iscomplexobj(A.data))
+        dt = np.complex128 if self.is_complex else np.float64
+        dev = torch.device(device)
+        t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a, dtype=d)).to(dev)  # noqa: E731
+        self.n = A.shape[0]
+        self._keep = [t(A.indptr, np.int64), t(A.indices, np.int32), t(A.data, dt), t(R.indptr, np.int64), t(R.indices, np.int32), t(R.data, dt)]
+        self.lpos = torch.full((self.n,), -1, dtype=torch.int32, device=dev)
+        self.c = _lib.hs_sparse_dev(self.n, *[C.c_void_p(x.data_ptr()) for x in self._keep])
+        self.device = dev
+
+
+class BlockOperator:
+    """``Op = [H1  A[g1,g2]; A[g2,g1]  H2]`` on the device, never formed (``hs_hss_blockop``): what ``_assemble_blocks`` builds from the children's
+    HSS Schur complements and the sparse couplings of ``A`` (factorization.jl:126-140).  ``gid``: 0-based global ids of the n1 + n2 indices."""
+
+    def __init__(self, H1, H2, gid, As):
+        self.H1, self.H2, self.As = H1, H2, As
+        self.n1 = H1.shape[0] if H1 is not None else 0
+        self.n2 = H2.shape[0] if H2 is not None else 0
+        self.gid = np.ascontiguousarray(gid, dtype=np.int64)
+        if self.gid.shape != (self.n1 + self.n2,):
+            raise _lib.DimensionMismatch(f"gid has {self.gid.shape} entries, the operator {self.n1 + self.n2} indices")
+        self.is_complex = As.is_complex
+        self.c = _lib.hs_hss_blockop(self.n1, self.n2, H1._h if H1 is not None else None, H2._h if H2 is not None else None,
+                                     self.gid.ctypes.data_as(_lib.p_i64), C.pointer(As.c), C.c_void_p(As.lpos.data_ptr()))
+
+    @property
+    def shape(self):
+        return (self.n1 + self.n2, self.n1 + self.n2)
+
+    def matmul(self, X, trans=False):
+        """``Op @ X`` (``trans``: ``Op.T @ X``) for a host block; staged through torch device tensors."""
+        import torch
+
+        n = self.n1 + self.n2
+        dt = np.complex128 if self.is_complex else np.float64
+        X2 = np.asarray(X).reshape(n, -1).astype(dt)
+        Xd = torch.from_numpy(np.ascontiguousarray(X2.T)).to(self.As.device)  # row-major q x n == column-major n x q
+        Yd = torch.zeros_like(Xd)
+        _lib.check(_lib.lib().hs_hss_blockop_apply(C.byref(self.c), int(self.is_complex), C.c_void_p(Xd.data_ptr()), n, C.c_void_p(Yd.data_ptr()), n,
+                                                   X2.shape[1], int(trans), None))
+        torch.cuda.synchronize(self.As.device)
+        Y = Yd.cpu().numpy().T
+        return Y[:, 0] if np.asarray(X).ndim == 1 else Y
+
+    def compress(self, cl=None, *, leafsize=64, atol=1e-6, rtol=1e-6, kest=64, seed=123, pad=8, level_scale=0.5, perm=None, update=None):
+        """HSS form of ``(Op - C @ M @ Z)[perm][:, perm]`` compressed from products and entries (``randcompress_adaptive`` on the operator,
+        factorization.jl:110,228-249); ``update = (C, M, Z)`` host arrays or ``None``."""
+        import torch
+
+        n = self.n1 + self.n2
+        first, n_cl, leaf = cl if cl is not None else (0, n, leafsize)
+        dt = np.complex128 if self.is_complex else np.float64
+        o = _lib.hs_hss_options(leaf, first, atol, rtol, kest, pad, seed, level_scale)
+        h = C.c_void_p()
+        L = _lib.lib()
+        f = L.hs_hss_compress_blockop_z if self.is_complex else L.hs_hss_compress_blockop_d
+        pp = None
+        if perm is not None:
+            perm = np.ascontiguousarray(perm, dtype=np.int64)
+            pp = perm.ctypes.data_as(_lib.p_i64)
+        args = [None, 0, None, 0, None, 0, 0, 0]
+        keep = []
+        if update is not None:
+            Cm, M, Z = (np.asarray(a).astype(dt) for a in update)
+            r1, r2 = M.shape
+            for a in (Cm, M, Z):
+                keep.append(torch.from_numpy(np.ascontiguousarray(a.T)).to(self.As.device))  # column-major on the device
+            args = [C.c_void_p(keep[0].data_ptr()), n, C.c_void_p(keep[1].data_ptr()), max(r1, 1), C.c_void_p(keep[2].data_ptr()), max(r2, 1), r1, r2]
+        _lib.check(f(C.byref(self.c), *args, pp, C.byref(o), None, C.byref(h)))
+        H = HssMatrix(h, self.is_complex)
+        H._operator = self  # the diagonal blocks are only read during the compression, but keep the inputs alive for inspection
+        return H

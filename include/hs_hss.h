@@ -94,10 +94,42 @@ int hs_hss_basis(hs_hss* H, int64_t node, double* out, int64_t ldo, int where);
 int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where);
 /* Y = H^T * X (plain transpose; the samples `X^T A` of an operator that contains H) */
 int hs_hss_mul_t(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where);
-/* `H.A11` (which = 0) / `H.A22` (which = 1) of the top-level split as an HSS matrix that SHARES H's generators (H must outlive it):
+/* `H.A11` (which = 0) / `H.A22` (which = 1) of the top-level split as an HSS matrix that SHARES H's generators (H must outlive it;
+ * which = 2: all of H as a view in cluster-tree order, i.e. without H's permutation):
  * what `_assemble_blocks` reads from a child's Schur complement (src/factorization.jl:127-135).  Its index space is the block's own,
  * 0 .. size-1 in cluster-tree order.  HS_ERR_HSS_LEAF when H is a single leaf (factorization.jl:164). */
 int hs_hss_child(hs_hss* H, int which, hs_hss** out);
+/* The off-diagonal blocks of the top-level split in low-rank form, A12 = C*Z (which = 0: C = U_1*B12 is n1 x r2, Z = U_2^T is r2 x n2) or
+ * A21 = C*Z (which = 1: C = U_2*B21 is n2 x r1, Z = U_1^T is r1 x n1): the factors `Uint = generators(S.A11)[1]*S.B12`, `Vbnd` that a parent
+ * front takes its low-rank couplings Aib, Abi from (src/factorization.jl:129-137).  Sizes and ranks: hs_hss_node_info of nodes 1 and 2. */
+int hs_hss_offdiag(hs_hss* H, int which, double* C, int64_t ldc, double* Z, int64_t ldz, int where);
+
+/* ---- operators that are never formed: two diagonal HSS blocks + sparse couplings (device only) -------------------------------------------
+ * The reference assembles the blocks of a compressed branch from its children's HSS Schur complements without densifying them
+ * (`_assemble_blocks`, src/factorization.jl:126-140): Aii = [S1.A11  A[int1,int2]; A[int2,int1]  S2.A11], Abb = [S1.A22  A[bnd1,bnd2];
+ * A[bnd2,bnd1]  S2.A22], and compresses `S = P(Abb - Abi*R)P'` from products (`_sample_schur!`, :238-244) and entries
+ * (`_getindex_schur`, :246-249).  hs_hss_blockop describes such an operator Op = [H1  A[g1,g2]; A[g2,g1]  H2] on the device. */
+typedef struct hs_sparse_dev { /* the sparse matrix A on the DEVICE, 0-based, as CSC and as CSR (both gather-form products) */
+  int64_t n;
+  const int64_t* colptr; const int32_t* rowval; const void* nzval;   /* CSC */
+  const int64_t* rowptr; const int32_t* colind; const void* nzval_r; /* CSR of the same matrix */
+} hs_sparse_dev;
+typedef struct hs_hss_blockop {
+  int64_t n1, n2;      /* sizes of the two parts; the operator's index space is [part 1; part 2] */
+  hs_hss* H1;          /* diagonal blocks (hs_hss_child views of the children's Schur complements); NULL for an empty part */
+  hs_hss* H2;
+  const int64_t* gid;  /* HOST: 0-based global DOF id (row/column of A) of every index, n1 + n2 entries */
+  const hs_sparse_dev* A;
+  int32_t* lpos;       /* DEVICE scratch of A->n ints, all -1 on entry; restored to -1 on return */
+} hs_hss_blockop;
+/* H ~= (Op - C*M*Z)[perm, perm] (C, M, Z on the device; r1 = 0 or r2 = 0: no update; perm on the host or NULL) */
+int hs_hss_compress_blockop_d(const hs_hss_blockop* op, const double* C, int64_t ldc, const double* M, int64_t ldm, const double* Z, int64_t ldz,
+                              int64_t r1, int64_t r2, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
+int hs_hss_compress_blockop_z(const hs_hss_blockop* op, const double* C, int64_t ldc, const double* M, int64_t ldm, const double* Z, int64_t ldz,
+                              int64_t r1, int64_t r2, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
+/* Y = Op*X (trans != 0: Op^T*X) on device blocks of nrhs columns, in the operator's index order */
+int hs_hss_blockop_apply(const hs_hss_blockop* op, int is_complex, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int trans, void* stream);
+
 /* ULV-type elimination of the HSS matrix (once), then B <- H^-1 B in place */
 int hs_hss_factor(hs_hss* H);
 int hs_hss_ldiv(hs_hss* H, double* B, int64_t ldb, int64_t nrhs, int where);

@@ -177,6 +177,8 @@ typedef struct hs_stats {
    * cases run the same tile code as `trsm_inv_kernel`): what a rocprofv3 --stats line of that kernel is compared with */
   double t_mfma_kernel;
   int64_t mfma_kernel_launches;
+  double gemm_bytes;     /* algorithmic bytes of those launches: A and B read once, C read and written once ((M*K + K*N + 2*M*N) * sizeof(T)
+                            summed over the fronts of every launch) -- what measured HBM traffic is compared with */
 } hs_stats;
 int hs_get_stats(const hs_handle* F, hs_stats* out);
 

@@ -3,8 +3,8 @@
 # (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots").  Units: KiB.
 # gfx950: FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced read -> doubled below.
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; rm -rf $R/gpurun_out/pmct; mkdir -p $R/gpurun_out/pmct; cd $R
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmct/f -- python3 tests/one_gemm.py $1 $2 $3 2 > gpurun_out/pmct/f.log 2>&1
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmct/w -- python3 tests/one_gemm.py $1 $2 $3 2 > gpurun_out/pmct/w.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmct/f -- python3 tools/one_gemm.py $1 $2 $3 2 > gpurun_out/pmct/f.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmct/w -- python3 tools/one_gemm.py $1 $2 $3 2 > gpurun_out/pmct/w.log 2>&1
 grep TF gpurun_out/pmct/f.log
 python3 - $1 $2 $3 <<'PY'
 import csv,sys,glob

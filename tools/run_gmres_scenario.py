@@ -1,7 +1,7 @@
 """The reference's scenario (test/rungmres.jl:15-52) on a generated problem: exact factorization, compressed
 factorization, GMRES(30) right-preconditioned by each.  Prints one JSON line per run (diagnostic, not a test).
 
-    python tests/run_gmres_scenario.py poisson3d_64 [swlevel] [tol] [swsize] [hss_min] [hss_dexp]
+    python tools/run_gmres_scenario.py poisson3d_64 [swlevel] [tol] [swsize] [hss_min] [hss_dexp]
 """
 import json
 import os
