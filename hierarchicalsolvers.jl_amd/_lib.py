@@ -23,7 +23,7 @@ class hs_options(C.Structure):
     _fields_ = [
         ("swlevel", i64), ("swsize", i64), ("atol", C.c_double), ("rtol", C.c_double), ("c_tol", C.c_double),
         ("leafsize", i64), ("kest", i64), ("stepsize", i64), ("verbose", C.c_uint8),
-        ("keep_schur", C.c_uint8), ("profile", C.c_uint8), ("split", C.c_uint8), ("hss_d", C.c_uint8), ("hss_dexp", C.c_uint8), ("reserved", C.c_uint8 * 2), ("seed", i64),
+        ("keep_schur", C.c_uint8), ("profile", C.c_uint8), ("split", C.c_uint8), ("hss_d", C.c_uint8), ("hss_dexp", C.c_uint8), ("mf", C.c_uint8), ("reserved", C.c_uint8 * 1), ("seed", i64),
     ]
 
 
@@ -76,7 +76,7 @@ EXPORTS = [
     "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free", "hs_node_schur_hss",
-    "hs_hss_offdiag", "hs_hss_compress_blockop_d", "hs_hss_compress_blockop_z", "hs_hss_blockop_apply",
+    "hs_hss_offdiag", "hs_hss_bytes", "hs_hss_compress_blockop_d", "hs_hss_compress_blockop_z", "hs_hss_blockop_apply",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_bisect_perm",
 ]
 
@@ -207,7 +207,7 @@ def lib():
     for f in (L.hs_hss_compress_lru_d, L.hs_hss_compress_lru_z):
         f.argtypes = [i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, C.c_int, p_i64, C.POINTER(hs_hss_options), vp, C.POINTER(vp)]
         f.restype = C.c_int
-    for f in (L.hs_hss_rank, L.hs_hss_size, L.hs_hss_samples, L.hs_hss_num_nodes):
+    for f in (L.hs_hss_rank, L.hs_hss_size, L.hs_hss_samples, L.hs_hss_num_nodes, L.hs_hss_bytes):
         f.argtypes = [vp]
         f.restype = i64
     L.hs_node_schur_hss.argtypes = [vp, i64, C.POINTER(hs_hss_options), C.POINTER(vp)]

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/hs_solver.h"
+#include "../../include/hs_hss.h"
 #include "hs_common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -132,6 +133,18 @@ struct NodeH {
   void* ht = nullptr;         // ni entries: D^-1 rhs[int] between the two sweeps of ldiv!
   int last_k = 0;             // samples the previous compression of D ended with
   std::vector<int64_t> ilv;   // interleaved order of the interior positions (empty: as assembled)
+  // hs_mffront.h: matrix-free compressed branch (hs_options.mf)
+  bool s_hss = false;          // the Schur complement of this front leaves as an HSS matrix
+  bool mf = false;             // both children hand over HSS Schur complements: the front is never assembled densely
+  void* S_hss = nullptr;       // hs_hss*: S[perm, perm], perm = [int_loc; bnd_loc], first split at n1p
+  int n1p = 0;                 // |int_loc|: boundary DOFs of this node that become interior at the parent
+  int last_ks = 0;             // samples the previous compression of S ended with
+  std::vector<int64_t> sperm;  // [int_loc; bnd_loc] as 0-based positions in this node's boundary
+  struct Coupling {            // entries of a sparse coupling block in block coordinates; e = position in nzval
+    std::vector<int> row, col;
+    std::vector<long long> e;
+    size_t size() const { return row.size(); }
+  } xr, xl;                    // A[int, bnd] / A[bnd, int] between the two children's parts (matrix-free fronts)
 };
 
 struct LevelH {
@@ -145,6 +158,7 @@ struct LevelH {
   std::vector<int> h_ni, h_nb;
   int ndense = 0;                          // the first ndense entries of `mine` are dense fronts (one batch), the rest compressed
   int nplain = 0;                          // of those, the first nplain keep a dense LU of D, the others an HSS form (hs_hssfront.h)
+  int nmf = 0;                             // the last nmf entries of `mine` are matrix-free fronts (hs_mffront.h): never assembled
   int dmaxni = 0, dmaxnb = 0, dmaxm = 0;   // extents of the dense batch
 };
 
@@ -182,6 +196,14 @@ struct hs_handle {
   int* d_pos = nullptr;
   int* d_owned = nullptr;   // 0-based ids of the DOFs this rank eliminates (hs_extract_owned: one launch)
   int64_t n_owned = 0;
+  // hs_options.mf: CSR form of A next to the CSC one (both products of the block operators are gather-form), operator index map
+  int64_t* d_rowptr = nullptr;
+  int32_t* d_colind = nullptr;
+  int64_t* d_tperm = nullptr;  // CSR entry -> CSC entry
+  void* d_nzr = nullptr;
+  int* d_lpos = nullptr;
+  bool mf_on = false;
+  double static_factor_bytes = 0.0;  // LF / UR / inverse blocks of the arena (the HSS and low-rank objects are counted per factorization)
   int64_t* d_colptr = nullptr;
   int32_t* d_rowval = nullptr;
   void* d_nz = nullptr;
@@ -219,10 +241,16 @@ static void free_lowrank_any(hs_handle* h);
 static void free_hss_any(hs_handle* h);
 static void free_handle(hs_handle* h) {
   if (!h) return;
+  for (auto& x : h->nodes)
+    if (x.S_hss) {
+      hs_hss_free((hs_hss*)x.S_hss);
+      x.S_hss = nullptr;
+    }
   free_hss_any(h);
   free_lowrank_any(h);
   void* ptrs[] = {h->d_fac,   h->d_inv, h->d_sb,    h->d_int, h->d_tmpi, h->d_colptr, h->d_rowval, h->d_nz,
-                  h->d_nodes, h->d_sc,  h->d_solve, h->d_w1,  h->d_w2,   h->d_part,   h->d_b,   h->d_owned};
+                  h->d_nodes, h->d_sc,  h->d_solve, h->d_w1,  h->d_w2,   h->d_part,   h->d_b,   h->d_owned,
+                  h->d_rowptr, h->d_colind, h->d_tperm, h->d_nzr, h->d_lpos};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -435,8 +463,12 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr, const SplitTr
 }
 
 static void dmalloc(void** p, size_t bytes, const char* what);
+template <class T>
+static void mf_compress_schur_dense(hs_handle* h, int id, const T* SB, int lds, const T* C_, int ldc, const T* M, int ldm, const T* Z, int ldz, int r1, int r2);
 #include "hs_compress.h"
 #include "hs_hssfront.h"
+#define MfCoupling NodeH::Coupling
+#include "hs_mffront.h"
 
 static double front_flops(double ni, double nb) { return (2.0 / 3.0) * ni * ni * ni + 2.0 * ni * ni * nb + 2.0 * ni * nb * nb; }
 
@@ -512,15 +544,31 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
                          : hss_bisect_perm(h->fidx_host.data() + x.off_fidx, x.ni, n, colptr, rowval, where);
       }
     }
+    if (opts.mf && nranks == 1 && !split.active && swlevel > 0 && !plan_only) {
+      // matrix-free compressed branch (hs_mffront.h): flagged fronts hand their Schur complement on as an HSS matrix, a parent of two
+      // such fronts is assembled from their generators and the sparse couplings of A
+      mf_plan(h, swlevel);
+      std::vector<int> where((size_t)n, -1);
+      for (int i = 0; i < h->nreal; ++i) {
+        NodeH& x = N[i];
+        if (!x.mf) continue;
+        h->mf_on = true;
+        x.hssd = false;  // the matrix-free form supersedes hs_options.hss_d
+        x.ilv = hss_bisect_perm(h->fidx_host.data() + x.off_fidx, x.ni, n, colptr, rowval, where);
+      }
+    }
     for (auto& L : h->levels) {  // dense fronts first: they are eliminated as one batch, compressed fronts one by one
       std::vector<int> ord;
-      for (int pass = 0; pass < 3; ++pass)
+      for (int pass = 0; pass < 4; ++pass)
         for (int id : L.mine)
-          if ((N[id].hssd ? 2 : (int)N[id].compressed) == pass) ord.push_back(id);
+          if ((N[id].mf ? 3 : (N[id].hssd ? 2 : (int)N[id].compressed)) == pass) ord.push_back(id);
       L.mine = ord;
       L.nplain = 0;
-      for (int id : L.mine)
-        if (N[id].compressed && !N[id].hssd) L.nplain++;
+      L.nmf = 0;
+      for (int id : L.mine) {
+        if (N[id].mf) L.nmf++;
+        else if (N[id].compressed && !N[id].hssd) L.nplain++;
+      }
       L.h_ni.clear();
       L.h_nb.clear();
       L.ndense = 0;
@@ -530,7 +578,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         x.batch_pos = (int)k;
         L.h_ni.push_back(x.ni);
         L.h_nb.push_back(x.nb);
-        if (!x.compressed && !x.hssd) {
+        if (!x.compressed && !x.hssd && !x.mf) {
           L.ndense = (int)k + 1;
           L.dmaxni = std::max(L.dmaxni, x.ni);
           L.dmaxnb = std::max(L.dmaxnb, x.nb);
@@ -558,11 +606,19 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         x.lds = rup(std::max(x.nb, 1), 2);
         if (x.mine || x.ghost) {
           x.off_SB = sb;
-          sb += rups((size_t)x.lds * x.nb, 32);
+          if (!(x.mf && x.s_hss)) sb += rups((size_t)x.lds * x.nb, 32);  // a matrix-free front whose S leaves as HSS never holds it densely
           x.off_cmap = ints;
           ints += x.nb;
         }
         if (!x.mine) continue;
+        if (x.mf) {  // no dense front, no dense factors: D, L, R, S live in the HSS / low-rank objects of hs_mffront.h
+          x.off_LF = x.off_UR = fac;
+          x.off_inv = x.off_inv256 = inv;
+          x.off_ipiv = x.off_rperm = ints;
+          x.off_cand = tmpi;
+          x.woff = woff;
+          continue;
+        }
         x.off_LF = fac;
         fac += rups((size_t)x.ldl * x.ni, 32);
         x.off_UR = fac;
@@ -695,6 +751,11 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         for (int e = 0; e < x.oni; ++e) sp[np[e]] = e;
       }
       HS_HIP(hipMemcpy(dint, hint.data(), ints * sizeof(int), hipMemcpyHostToDevice));
+      if (h->mf_on) mf_sperm(h, hint);
+    }
+    if (h->mf_on) {
+      mf_couplings(h, n, colptr, rowval);
+      mf_build_csr(h, n, colptr, rowval);
     }
     if (nranks > 1) {  // the DOFs this rank eliminates, as one index list
       std::vector<int> owned;
@@ -751,7 +812,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           q.ni = x.ni; q.nb = x.nb; q.m = x.m; q.ldl = x.ldl; q.ldu = x.ldu;
           q.compressed = x.compressed ? 1 : 0;
           q.mrows = x.compressed ? x.ni : x.m;
-          if (x.hssd) q.ni = q.nb = q.m = q.mrows = 0;  // the dense sweeps skip it: solve_hss_fwd / solve_hss_bwd (hs_hssfront.h)
+          if (x.hssd || x.mf) q.ni = q.nb = q.m = q.mrows = 0;  // the dense sweeps skip it: solve_hss_fwd / solve_hss_bwd (hs_hssfront.h)
           q.woff = x.woff;
           q.poff = poff;
           poff += (long long)((x.nb + 511) / 512) * x.ni;
@@ -761,7 +822,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
             int c = side == 0 ? x.left : x.right;
             if (x.leaf || c < 0) continue;
             const NodeH& ch = N[c];
-            if (ch.nb == 0) continue;
+            if (ch.nb == 0 || x.mf) continue;  // a matrix-free front reads its children's generators, not their dense S
             ScatterDesc<T> sc;
             sc.S = dsb + ch.off_SB;
             sc.cmap = dint + ch.off_cmap;
@@ -799,6 +860,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     st.bytes_solve += 3.0 * n * sizeof(T);
     st.flops_factor = h->flops * (h->is_complex ? 4.0 : 1.0);
     st.bytes_factors = (double)(fac + inv) * sizeof(T);
+    h->static_factor_bytes = st.bytes_factors;
     return h;
   } catch (...) {
     free_handle(h);
@@ -822,8 +884,10 @@ static void numeric_begin(hs_handle* h, const void* nzval, int on_device) {
   if (!nzval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: nzval == NULL");
   hipStream_t s = h->stream;
   free_hss_nodes<T>(h);
+  free_mf_nodes<T>(h);
   free_lowrank_nodes<T>(h);
   HS_HIP(hipMemcpyAsync(h->d_nz, nzval, h->nnz * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  if (h->mf_on) launch_perm_gather<T>((const T*)h->d_nz, h->d_tperm, (T*)h->d_nzr, h->nnz, s);
   HS_HIP(hipMemsetAsync(h->d_own, 0xff, h->n * sizeof(int), s));
   h->prof = Profiler();
   h->prof.on = h->opts.profile != 0;
@@ -847,7 +911,7 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     LevelH& L = h->levels[lv];
     if (L.mine.empty()) continue;
     const NodeDesc<T>* dn = dn_all + L.desc_off;
-    const int nb_ = (int)L.mine.size();
+    const int nb_ = (int)L.mine.size() - L.nmf;  // the fronts that are assembled densely (matrix-free fronts come last in `mine`)
     static const bool progress = getenv("HS_PROGRESS") != nullptr;  // one line per level as it is enqueued (long profiler runs)
     if (progress) fprintf(stderr, "[hs] enqueue level %d (%d fronts)\n", lv, nb_);
     // Optimistic pivoting (Sched::optimistic): the dense fronts of the level are first eliminated with every panel
@@ -895,6 +959,11 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     }
     if (L.nplain > 0) factor_compressed_level<T>(h, L.mine.data() + L.ndense, L.nplain, dn + L.ndense, (const SolveNode<T>*)h->d_solve + L.desc_off + L.ndense);  // hs_compress.h
     if (nb_ > L.ndense + L.nplain) factor_hss_fronts<T>(h, L.mine.data() + L.ndense + L.nplain, nb_ - L.ndense - L.nplain, dn + L.ndense + L.nplain);  // hs_hssfront.h
+    for (int k = 0; k < L.ndense; ++k) {  // F2: a flagged front eliminated densely (a leaf) still hands its S on as an HSS matrix (factorization.jl:45-59)
+      const NodeH& x = h->nodes[L.mine[k]];
+      if (x.s_hss) mf_compress_schur_dense<T>(h, L.mine[k], x.ext_sb ? (const T*)x.ext_sb : dsb + x.off_SB, x.lds, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0);
+    }
+    if (L.nmf > 0) factor_mf_fronts<T>(h, L.mine.data() + nb_, L.nmf);  // hs_mffront.h
     static const bool lvl_env = getenv("HS_VERBOSE_LEVELS") != nullptr;
     if (h->opts.profile || lvl_env) {  // per-level wall time (HS_VERBOSE_LEVELS=1 prints it at hs_numeric_end)
       hipEvent_t e = nullptr;
@@ -950,6 +1019,17 @@ static void numeric_end(hs_handle* h) {
   h->stats.gemm_flops = prof.flops[HS_CAT_GEMM];
   h->stats.gemm_launches = prof.launches[HS_CAT_GEMM];
   h->stats.gemm_bytes = prof.gemm_bytes;
+  {  // bytes the factors hold: the dense arena + the HSS / low-rank objects of the compressed fronts of this factorization
+    double dyn = 0.0;
+    const double esz = h->is_complex ? 16.0 : 8.0;
+    for (const NodeH& x : h->nodes) {
+      if (x.hss) dyn += (double)hs_hss_bytes((const hs_hss*)x.hss);
+      if (x.S_hss) dyn += (double)hs_hss_bytes((const hs_hss*)x.S_hss);
+      if (x.hW) dyn += (double)x.hldw * std::max(x.last_rR, 0) * esz;
+      dyn += ((double)x.nb + x.ni) * (std::max(x.last_rL, 0) + std::max(x.last_rR, 0)) * esz * ((x.lrL || x.lrR) ? 1.0 : 0.0);
+    }
+    h->stats.bytes_factors = h->static_factor_bytes + dyn;
+  }
   std::vector<int> info(h->nnodes);
   HS_HIP(hipMemcpy(info.data(), h->d_info, h->nnodes * sizeof(int), hipMemcpyDeviceToHost));
   for (int i = 0; i < h->nnodes; ++i)
@@ -1314,7 +1394,7 @@ extern "C" int hs_node_info(const hs_handle* F, int64_t node, int64_t* ni, int64
 template <class T>
 static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) {
   if (!x.mine) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: node is owned by rank %d", x.owner);
-  if (x.hssd) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "the interior block of this node is an HSS matrix (hs_options.hss_d): it has no dense D, L, R blocks");
+  if (x.hssd || x.mf) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "the interior block of this node is an HSS matrix (hs_options.hss_d / mf): it has no dense D, L, R blocks");
   if (x.compressed && (which == HS_BLK_LBI || which == HS_BLK_UIB)) {  // dense reconstruction C*Z of the low-rank transform
     const void* lr = which == HS_BLK_LBI ? x.lrL : x.lrR;
     if (!lr) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: node has no compressed Gauss transforms yet");

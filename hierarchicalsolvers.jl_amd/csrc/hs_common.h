@@ -226,6 +226,20 @@ void launch_pack_idx(const int* idx, int cnt, const void* b, void* buf, int esz,
 void launch_unpack_idx(const int* idx, int cnt, void* b, const void* buf, int esz, hipStream_t s);  // b[idx[i]] = buf[i]
 void launch_copy_idx(const int* idx, int cnt, const void* b, void* out, int esz, hipStream_t s);      // out[idx[i]] = b[idx[i]]
 
+// matrix-free compressed fronts (kernels_mf.hip)
+struct HsFillEntry {
+  int row, col;  // destination in a zero-filled dense block
+  long long e;   // >= 0: the value is nz[e]; < 0: one
+};
+template <class T>
+void launch_fill_entries(const HsFillEntry* ent, int cnt, const T* nz, T* out, int ld, hipStream_t s);
+template <class T>
+void launch_identity_cols(T* X, int ld, int n, int c0, int cols, hipStream_t s);
+template <class T>
+void launch_perm_gather(const T* src, const int64_t* perm, T* dst, int64_t cnt, hipStream_t s);
+template <class T>
+void launch_transpose(const T* in, int ldi, T* out, int ldo, int rows, int cols, hipStream_t s);
+
 void hs_set_error(int code, long long info, const char* fmt, ...);
 
 #define HS_HIP(call)                                                                          \

@@ -199,6 +199,8 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
           gp[i] = GemmProb<T>{LL[i]->Z, W[i], W2[i], rL, rR, ni, LL[i]->ldz, RR[i]->ldc, ldw2};
           gp[count + i] = GemmProb<T>{W2[i], RR[i]->Z, W3[i], rL, nb, rR, ldw2, RR[i]->ldz, ldw2};
           gp[2 * count + i] = GemmProb<T>{LL[i]->Cd, W3[i], hd[i].SB, nb, nb, rL, LL[i]->ldc, ldw2, hd[i].lds};
+          if (h->nodes[ids[i]].s_hss)  // hs_options.mf: S is compressed from the operator Abb - C_L*(Z_L*W)*Z_R below, never formed
+            gp[count + i] = gp[2 * count + i] = GemmProb<T>{nullptr, nullptr, nullptr, 0, 0, 0, 2, 2, 2};
           mrL = std::max(mrL, rL);
           mrR = std::max(mrR, rR);
         }
@@ -210,8 +212,16 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
           launch_gemm_probs<T>(dgp + 2 * count, count, maxnb, maxnb, 1, s);
         }
         lap("E: Schur update");
+        for (int i = 0; i < count; ++i) {  // the transition of the matrix-free branch: `randcompress_adaptive` on the Schur operator (factorization.jl:108-110)
+          if (!h->nodes[ids[i]].s_hss || !W2[i]) continue;
+          const int ldw2 = (LL[i]->r + 1) / 2 * 2;
+          mf_compress_schur_dense<T>(h, ids[i], hd[i].SB, hd[i].lds, LL[i]->Cd, LL[i]->ldc, W2[i], ldw2, RR[i]->Z, RR[i]->ldz, LL[i]->r, RR[i]->r);
+        }
+        lap("S: HSS compression of the Schur operator");
       }
     }
+    for (int i = 0; i < count; ++i)  // fronts without a low-rank update (a rank came out 0): S = Abb as assembled
+      if (h->nodes[ids[i]].s_hss && !h->nodes[ids[i]].S_hss) mf_compress_schur_dense<T>(h, ids[i], hd[i].SB, hd[i].lds, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0);
     // F. Z_L' = Z_L * U^-1 (Z_L is consumed)
     {
       std::vector<RtrsmJob<T>> rj(count);
@@ -276,7 +286,7 @@ static void solve_lr_fwd(hs_handle* h, int lv, T* db, hipStream_t s) {
   T* w2 = (T*)h->d_w2;  // y = L11^-1 P rhs[int]
   for (int id : L.mine) {
     const NodeH& x = h->nodes[id];
-    if (!x.compressed || !x.lrL || x.hssd) continue;
+    if (!x.compressed || !x.lrL || x.hssd || x.mf) continue;
     const LowRank<T>& lr = *(const LowRank<T>*)x.lrL;
     if (lr.r == 0) continue;
     ensure_lr_workspace<T>(h, lr.r, lr.cols);
@@ -292,7 +302,7 @@ static void solve_lr_bwd(hs_handle* h, int lv, T* db, hipStream_t s) {
   T* w1 = (T*)h->d_w1;
   for (int id : L.mine) {
     const NodeH& x = h->nodes[id];
-    if (!x.compressed || !x.lrR || x.hssd) continue;
+    if (!x.compressed || !x.lrR || x.hssd || x.mf) continue;
     const LowRank<T>& lr = *(const LowRank<T>*)x.lrR;
     if (lr.r == 0) continue;
     ensure_lr_workspace<T>(h, lr.r, lr.cols);

@@ -1479,6 +1479,14 @@ extern "C" int hs_hss_set_stream(hs_hss* H, void* stream) {
 
 extern "C" int64_t hs_hss_size(const hs_hss* H) { return H ? HSS_DISPATCH(H, HD(H)->n, HZ(H)->n) : 0; }
 extern "C" int64_t hs_hss_samples(const hs_hss* H) { return H ? HSS_DISPATCH(H, HD(H)->k, HZ(H)->k) : 0; }
+template <class T>
+static int64_t bytes_of(const HssT<T>* H) {
+  int64_t b = 0;
+  for (auto& pr : H->keep.v) b += (int64_t)pr.second;
+  for (auto& pr : H->permpool.v) b += (int64_t)pr.second;
+  return b;
+}
+extern "C" int64_t hs_hss_bytes(const hs_hss* H) { return H ? HSS_DISPATCH(H, bytes_of(HD(H)), bytes_of(HZ(H))) : 0; }
 extern "C" int64_t hs_hss_num_nodes(const hs_hss* H) { return H ? (int64_t)HSS_DISPATCH(H, HD(H)->nd.size(), HZ(H)->nd.size()) : 0; }
 extern "C" double hs_hss_time(const hs_hss* H, int what) {
   if (!H) return 0.0;

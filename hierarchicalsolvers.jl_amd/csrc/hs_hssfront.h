@@ -303,7 +303,7 @@ static void solve_hss_fwd(hs_handle* h, int lv, T* db, hipStream_t s) {
   const LevelH& L = h->levels[lv];
   for (int id : L.mine) {
     const NodeH& x = h->nodes[id];
-    if (!x.hssd || !x.hss) continue;
+    if (!(x.hssd || x.mf) || !x.hss) continue;
     T* t = (T*)x.ht;
     launch_pack_idx(h->d_int + x.off_fidx, x.ni, db, t, (int)sizeof(T), s);
     int st = hs_hss_set_stream((hs_hss*)x.hss, (void*)s);
@@ -324,7 +324,7 @@ static void solve_hss_bwd(hs_handle* h, int lv, T* db, hipStream_t s) {
   const LevelH& L = h->levels[lv];
   for (int id : L.mine) {
     const NodeH& x = h->nodes[id];
-    if (!x.hssd || !x.hss) continue;
+    if (!(x.hssd || x.mf) || !x.hss) continue;
     T* t = (T*)x.ht;
     if (x.nb > 0 && x.lrR && x.hW) {
       const LowRank<T>& lr = *(const LowRank<T>*)x.lrR;

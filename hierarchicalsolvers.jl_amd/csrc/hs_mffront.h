@@ -1,0 +1,417 @@
+// hs_mffront.h -- the MATRIX-FREE compressed branch: Schur complements travel between fronts as HSS matrices (hs_options.mf).
+//
+// Reference: `_factor_branch(..., Val(true))` (src/factorization.jl:78-112) with HSS children:
+//   C3  `_assemble_blocks` for HssMatrix children (:126-140): Aii = [S1.A11 A[int1,int2]; A[int2,int1] S2.A11], Aib / Abi = the
+//       children's off-diagonal generators (`U*B12`, `V`) + sparse couplings, Abb = [S1.A22 A[bnd1,bnd2]; A[bnd2,bnd1] S2.A22] --
+//       nothing is densified;
+//   B2' `D = blockfactor(Aii)` over HSS blocks (src/blockmatrix.jl:121-130), every later `Aii^-1 X` through HSS solves (:134-156);
+//   C5  Gauss transforms from the children's generators, the sparse coupling `X = [0 A12; A21 0]` factored on its own and
+//       appended (:184-209); nothing is recompressed (`_recompress!` is commented out, :194,207);
+//   C6  `S = P (Abb - Abi*R) P'` handed to `randcompress_adaptive` as an operator with products (`_sample_schur!`, :238-244) and
+//       entries (`_getindex_schur`, :246-249), over `bisection_cluster((|int_loc|, |bnd|))` (:109-110);
+//   F2  a flagged leaf: `compress(S[perm,perm], cl, cl)` (:45-59);
+// and the TRANSITION (a flagged branch whose children are dense): dense blocks, `pqrfact` Gauss transforms, `S` compressed from the
+// same operator (:99-110) -- hs_compress.h eliminates such a front, then `S` leaves through hs_hss_compress_lru instead of being formed.
+//
+// Formulation of `D`: ONE HSS matrix over a recursive-bisection order of the front's interior graph, compressed matrix-free from the
+// operator [S1.A11 A12; A21 S2.A11] (hs_hss_blockop: two HSS products + a sparse product per sample, batched HSS entry access + a sparse
+// gather per block) -- oracle/hs_oracle_mf.py `dmode="single"`.  The reference's 2x2 `BlockFactorization` needs `A11 \ A12` in HSS-by-HSS
+// arithmetic (HssMatrices.jl, absent from the reference tree); `_equilibrate_clusters` (C2, :143-168) exists to make the two children's
+// cluster trees compatible for that arithmetic and has no role here: every compression samples an operator.  `L = Abi*Aii^-1` is applied
+// as `Abi_lr * (D^-1 x)` in `ldiv!` (one HSS solve serves `_dsolve!` and `_lsolve!`), so no transposed HSS solve is needed.
+// PARITY UNPINNED (HssMatrices.jl / LowRankApprox.jl are not part of the reference tree); checked against oracle/hs_oracle_mf.py.
+#pragma once
+#include "../../include/hs_hss.h"
+#include "hs_lowrank.h"
+
+// MfCoupling = NodeH::Coupling (hs_api.hip): entries of a sparse coupling block in block coordinates, e = 0-based position in nzval
+
+static int mf_hss_leaf(const hs_options& o) {
+  static const int env = getenv("HS_HSS_LEAF") ? atoi(getenv("HS_HSS_LEAF")) : 0;
+  return env > 0 ? std::max(32, env) : std::max<int>(128, (int)o.leafsize);
+}
+
+// ---- analysis: which Schur complements leave as HSS, which fronts are matrix-free, sparse coupling lists ---------------------------------
+static void mf_plan(hs_handle* h, int64_t swlevel) {
+  std::vector<NodeH>& N = h->nodes;
+  const int leaf = mf_hss_leaf(h->opts);
+  auto wants = [&](const NodeH& x) {  // compression_flag of factorization.jl:15 (a flagged LEAF compresses its S too, :45-59)
+    return x.level >= 2 && x.level <= swlevel && x.nb >= h->opts.swsize && x.nb > leaf && x.ni > 0 && x.mine && x.parent >= 0 && N[x.parent].level >= 1;
+  };
+  for (int i = 0; i < h->nreal; ++i) {
+    NodeH& x = N[i];
+    if (x.leaf || x.right < 0) continue;
+    if (wants(N[x.left]) && wants(N[x.right])) {  // both or none: a parent assembles matrix-free from two HSS children
+      N[x.left].s_hss = N[x.right].s_hss = true;
+      x.mf = true;
+    }
+  }
+}
+
+// the order [int_loc; bnd_loc] of a node's boundary (factorization.jl:41,56-57,108) and |int_loc|, from its cmap
+static void mf_sperm(hs_handle* h, const std::vector<int>& hint) {
+  for (int i = 0; i < h->nreal; ++i) {
+    NodeH& x = h->nodes[i];
+    if (!x.s_hss) continue;
+    const int* cm = hint.data() + x.off_cmap;
+    const NodeH& p = h->nodes[x.parent];
+    x.sperm.resize((size_t)x.nb);
+    for (int e = 0; e < x.nb; ++e) x.sperm[(size_t)e] = e;
+    std::stable_sort(x.sperm.begin(), x.sperm.end(), [&](int64_t a, int64_t b) { return cm[a] < cm[b]; });
+    x.n1p = 0;
+    for (int e = 0; e < x.nb; ++e) x.n1p += cm[e] >= 0 && cm[e] < p.ni;
+  }
+}
+
+// sparse couplings A[int, bnd] / A[bnd, int] between the two children's parts of a matrix-free front (1-based CSC pattern of A)
+static void mf_couplings(hs_handle* h, int64_t n, const int64_t* colptr, const int64_t* rowval) {
+  std::vector<int> where((size_t)n, -1);
+  for (int i = 0; i < h->nreal; ++i) {
+    NodeH& x = h->nodes[i];
+    if (!x.mf) continue;
+    const int* F = h->fidx_host.data() + x.off_fidx;
+    for (int p = 0; p < x.m; ++p) where[F[p]] = p;
+    auto part = [&](int p) { return p < x.ni ? (p < x.ni1 ? 1 : 2) : ((p - x.ni) < x.nb1 ? 1 : 2); };
+    for (int c = 0; c < x.m; ++c) {
+      const int64_t g = F[c];
+      for (int64_t e = colptr[g] - 1; e < colptr[g + 1] - 1; ++e) {
+        const int p = where[rowval[e] - 1];
+        if (p < 0 || part(p) == part(c)) continue;
+        if (p < x.ni && c >= x.ni) {
+          x.xr.row.push_back(p); x.xr.col.push_back(c - x.ni); x.xr.e.push_back(e);
+        } else if (p >= x.ni && c < x.ni) {
+          x.xl.row.push_back(p - x.ni); x.xl.col.push_back(c); x.xl.e.push_back(e);
+        }
+      }
+    }
+    for (int p = 0; p < x.m; ++p) where[F[p]] = -1;
+  }
+}
+
+// CSR form of A (pattern on the host -> device; the values follow by a fixed permutation of the CSC values in hs_numeric_begin)
+static void mf_build_csr(hs_handle* h, int64_t n, const int64_t* colptr, const int64_t* rowval) {
+  const int64_t nnz = colptr[n] - 1;
+  std::vector<int64_t> rp((size_t)n + 1, 0), tp((size_t)nnz);
+  std::vector<int32_t> ci((size_t)nnz);
+  for (int64_t e = 0; e < nnz; ++e) rp[(size_t)rowval[e]]++;  // rowval is 1-based: counts land at index r+1
+  for (int64_t r = 0; r < n; ++r) rp[(size_t)r + 1] += rp[(size_t)r];
+  std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+  for (int64_t c = 0; c < n; ++c)
+    for (int64_t e = colptr[c] - 1; e < colptr[c + 1] - 1; ++e) {
+      const int64_t r = rowval[e] - 1, at = fill[(size_t)r]++;
+      ci[(size_t)at] = (int32_t)c;
+      tp[(size_t)at] = e;
+    }
+  dmalloc((void**)&h->d_rowptr, sizeof(int64_t) * ((size_t)n + 1), "rowptr");
+  dmalloc((void**)&h->d_colind, sizeof(int32_t) * (size_t)nnz, "colind");
+  dmalloc((void**)&h->d_tperm, sizeof(int64_t) * (size_t)nnz, "CSR value permutation");
+  dmalloc(&h->d_nzr, (size_t)nnz * (h->is_complex ? 16 : 8), "CSR values");
+  dmalloc((void**)&h->d_lpos, sizeof(int) * (size_t)n, "operator index map");
+  HS_HIP(hipMemcpy(h->d_rowptr, rp.data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+  HS_HIP(hipMemcpy(h->d_colind, ci.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+  HS_HIP(hipMemcpy(h->d_tperm, tp.data(), sizeof(int64_t) * (size_t)nnz, hipMemcpyHostToDevice));
+  HS_HIP(hipMemset(h->d_lpos, 0xff, sizeof(int) * (size_t)n));
+}
+
+template <class T>
+static void free_mf_nodes(hs_handle* h) {
+  for (auto& x : h->nodes) {
+    if (x.S_hss) {
+      hs_hss_free((hs_hss*)x.S_hss);
+      x.S_hss = nullptr;
+    }
+  }
+}
+
+static hs_hss_options mf_options(const hs_handle* h, int node, double scale, int64_t first_split, int last_k, int n) {
+  hs_hss_options o;
+  hs_hss_options_default(&o);
+  o.leafsize = mf_hss_leaf(h->opts);
+  o.first_split = first_split;
+  o.atol = h->opts.atol * scale;
+  o.rtol = h->opts.rtol * scale;
+  int64_t k0 = 128;
+  while (k0 < 4.0 * std::sqrt((double)n)) k0 *= 2;
+  o.kest = last_k > 0 ? last_k : (h->opts.kest > 0 ? h->opts.kest : k0);
+  o.seed = h->opts.seed + 31 * (int64_t)node;
+  return o;
+}
+
+static void mf_check(int st) {
+  if (st != 0) throw HsError{st};
+}
+
+// S of a front that was eliminated on its dense front (a transition branch or a flagged leaf) leaves as an HSS matrix:
+// H ~= (SB - C*M*Z)[perm, perm], perm = [int_loc; bnd_loc], first split at |int_loc| (factorization.jl:56-57,108-110)
+template <class T>
+static void mf_compress_schur_dense(hs_handle* h, int id, const T* SB, int lds, const T* C_, int ldc, const T* M, int ldm, const T* Z, int ldz, int r1, int r2) {
+  NodeH& x = h->nodes[id];
+  const int64_t fs = (x.n1p > 0 && x.n1p < x.nb) ? x.n1p : 0;
+  hs_hss_options o = mf_options(h, id, 1.0, fs, x.last_ks, x.nb);
+  hs_hss* H = nullptr;
+  const int st = h->is_complex ? hs_hss_compress_lru_z(x.nb, (const double*)SB, lds, (const double*)C_, ldc, (const double*)M, ldm, (const double*)Z, ldz, r1, r2, 1,
+                                                       x.sperm.data(), &o, h->stream, &H)
+                               : hs_hss_compress_lru_d(x.nb, (const double*)SB, lds, (const double*)C_, ldc, (const double*)M, ldm, (const double*)Z, ldz, r1, r2, 1,
+                                                       x.sperm.data(), &o, h->stream, &H);
+  mf_check(st);
+  x.S_hss = H;
+  x.last_ks = (int)hs_hss_samples(H);
+  h->maxrank = std::max<int64_t>(h->maxrank, hs_hss_rank(H));
+  if (h->opts.verbose) fprintf(stderr, "[hs] node %d (level %d, nb=%d): hssrank(S)=%lld (%lld samples)\n", id, x.level, x.nb, (long long)hs_hss_rank(H), (long long)hs_hss_samples(H));
+}
+
+// the blocks of one child's Schur complement a parent reads (factorization.jl:127-135): S.A11 / S.A22 as views sharing the generators
+struct MfChild {
+  hs_hss* S = nullptr;
+  hs_hss* a11 = nullptr;
+  hs_hss* a22 = nullptr;
+  int n1 = 0, n2 = 0, r12 = 0, r21 = 0;  // sizes of the two blocks, ranks of A12 = C*Z (r12 = rank of the bnd basis) and A21
+  ~MfChild() { close(); }
+  void close() {
+    if (a11) hs_hss_free(a11);
+    if (a22) hs_hss_free(a22);
+    a11 = a22 = nullptr;
+  }
+  void open(hs_hss* S_, int n1_, int nb) {
+    S = S_;
+    n1 = n1_;
+    n2 = nb - n1_;
+    if (n1 > 0 && n2 > 0) {
+      mf_check(hs_hss_child(S, 0, &a11));
+      mf_check(hs_hss_child(S, 1, &a22));
+      int64_t i1[8], i2[8];
+      mf_check(hs_hss_node_info(S, 1, i1));
+      mf_check(hs_hss_node_info(S, 2, i2));
+      r12 = (int)i2[6];  // A12 = (U_1 B12) U_2^T
+      r21 = (int)i1[6];  // A21 = (U_2 B21) U_1^T
+    } else if (n1 > 0) {
+      mf_check(hs_hss_child(S, 2, &a11));
+    } else {
+      mf_check(hs_hss_child(S, 2, &a22));
+    }
+  }
+};
+
+template <class T>
+struct MfBuf {  // device buffers of one front's elimination, freed on every exit path
+  std::vector<void*> p;
+  ~MfBuf() {
+    for (void* q : p)
+      if (q) (void)hipFree(q);
+  }
+  T* get(size_t elems, const char* what) {
+    void* q = nullptr;
+    dmalloc(&q, (elems + 32) * sizeof(T), what);
+    p.push_back(q);
+    return (T*)q;
+  }
+  void release(void* q) {  // ownership moves to the caller
+    for (auto& e : p)
+      if (e == q) e = nullptr;
+  }
+};
+
+// exact factorization of a sparse coupling block X (rows x cols, few entries) by its nonzero rows or columns, whichever are fewer:
+// X = C*Z with unit entries in one factor and the values in the other; returns the rank and the fill lists (positions relative to
+// the column offset c_off of C and the row offset c_off of Z)
+static int mf_factor_coupling(const MfCoupling& X, int c_off, std::vector<HsFillEntry>& fc, std::vector<HsFillEntry>& fz) {
+  if (X.size() == 0) return 0;
+  std::vector<int> rows(X.row), cols(X.col);
+  std::sort(rows.begin(), rows.end());
+  rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+  std::sort(cols.begin(), cols.end());
+  cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+  const bool by_rows = rows.size() <= cols.size();
+  const std::vector<int>& key = by_rows ? rows : cols;
+  auto idx = [&](int v) { return (int)(std::lower_bound(key.begin(), key.end(), v) - key.begin()); };
+  if (by_rows) {  // C[r, k(r)] = 1, Z[k(r), c] = value
+    for (size_t k = 0; k < rows.size(); ++k) fc.push_back(HsFillEntry{rows[k], c_off + (int)k, -1});
+    for (size_t t = 0; t < X.size(); ++t) fz.push_back(HsFillEntry{c_off + idx(X.row[t]), X.col[t], X.e[t]});
+  } else {  // C[r, k(c)] = value, Z[k(c), c] = 1
+    for (size_t t = 0; t < X.size(); ++t) fc.push_back(HsFillEntry{X.row[t], c_off + idx(X.col[t]), X.e[t]});
+    for (size_t k = 0; k < cols.size(); ++k) fz.push_back(HsFillEntry{c_off + (int)k, cols[k], -1});
+  }
+  return (int)key.size();
+}
+
+template <class T>
+static void mf_fill(hs_handle* h, const std::vector<HsFillEntry>& f, T* out, int ld, MfBuf<T>& buf) {
+  if (f.empty()) return;
+  HsFillEntry* d = (HsFillEntry*)buf.get((f.size() * sizeof(HsFillEntry) + sizeof(T) - 1) / sizeof(T), "coupling entries");
+  HS_HIP(hipMemcpyAsync(d, f.data(), f.size() * sizeof(HsFillEntry), hipMemcpyHostToDevice, h->stream));
+  HS_HIP(hipStreamSynchronize(h->stream));
+  launch_fill_entries<T>(d, (int)f.size(), (const T*)h->d_nz, out, ld, h->stream);
+}
+
+// ---- numeric: the matrix-free fronts of one level, one at a time (they are the few large fronts at the top of the tree) --------------
+template <class T>
+static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
+  hipStream_t s = h->stream;
+  static const bool vt = getenv("HS_VERBOSE_COMPRESS") != nullptr;
+  const bool say = h->opts.verbose || vt;
+  hs_sparse_dev As{h->n, h->d_colptr, h->d_rowval, h->d_nz, h->d_rowptr, h->d_colind, h->d_nzr};
+  const double dsc = std::pow(10.0, -(double)(h->opts.hss_dexp == 0 ? 2 : h->opts.hss_dexp - 1));  // hs_options.hss_dexp
+  for (int k = 0; k < count; ++k) {
+    const int id = ids[k];
+    NodeH& x = h->nodes[id];
+    NodeH &c1 = h->nodes[x.left], &c2 = h->nodes[x.right];
+    if (!c1.S_hss || !c2.S_hss) HS_FAIL(HS_ERR_ARGUMENT, id, "internal: node %d is matrix-free but a child holds no HSS Schur complement", id);
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!vt) return;
+      (void)hipStreamSynchronize(s);
+      auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[hs mf] node %d (level %d, ni=%d, nb=%d): %-30s %9.3f ms\n", id, x.level, x.ni, x.nb, what, std::chrono::duration<double, std::milli>(now - t0).count());
+      t0 = now;
+    };
+    MfChild ch1, ch2;
+    ch1.open((hs_hss*)c1.S_hss, c1.n1p, c1.nb);
+    ch2.open((hs_hss*)c2.S_hss, c2.n1p, c2.nb);
+    if (ch1.n1 != x.ni1 || ch1.n1 + ch2.n1 != x.ni || ch1.n2 != x.nb1 || ch1.n2 + ch2.n2 != x.nb)
+      HS_FAIL(HS_ERR_DIMENSION, id, "internal: children of node %d contribute (%d+%d, %d+%d) DOFs, expected (%d, %d)", id, ch1.n1, ch2.n1, ch1.n2, ch2.n2, x.ni, x.nb);
+    std::vector<int64_t> gid((size_t)x.m);
+    for (int p = 0; p < x.m; ++p) gid[(size_t)p] = h->fidx_host[x.off_fidx + p];
+    MfBuf<T> buf;
+    // ---- D = Aii as one HSS matrix, compressed from the operator [S1.A11 A[int1,int2]; A[int2,int1] S2.A11] ------------------------------
+    {
+      hs_hss_blockop op{ch1.n1, ch2.n1, ch1.a11, ch2.a11, gid.data(), &As, (int32_t*)h->d_lpos};
+      hs_hss_options o = mf_options(h, id, dsc, 0, x.last_k, x.ni);
+      hs_hss* D = nullptr;
+      const int64_t* q = x.ilv.empty() ? nullptr : x.ilv.data();
+      mf_check(h->is_complex ? hs_hss_compress_blockop_z(&op, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, q, &o, s, &D)
+                             : hs_hss_compress_blockop_d(&op, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, q, &o, s, &D));
+      x.hss = D;
+      lap("D: compress(Aii) matrix-free");
+      int st = hs_hss_factor(D);
+      if (st != 0) {
+        if (st == HS_ERR_SINGULAR) hs_set_error(HS_ERR_SINGULAR, id, "SingularException: the HSS form of the interior block of node %d is singular", id);
+        throw HsError{st};
+      }
+      lap("D: HSS elimination");
+      x.last_k = (int)hs_hss_samples(D);
+      h->maxrank = std::max<int64_t>(h->maxrank, hs_hss_rank(D));
+      if (say) fprintf(stderr, "[hs] node %d (level %d, ni=%d, nb=%d): hssrank(D)=%lld (%lld samples), matrix-free\n", id, x.level, x.ni, x.nb, (long long)hs_hss_rank(D), (long long)hs_hss_samples(D));
+      if (!x.ht) dmalloc(&x.ht, ((size_t)x.ni + 32) * sizeof(T), "HSS solve vector");
+    }
+    // the children's Schur complements are released once absorbed (the reference keeps every S although only the root's is used)
+    auto release_children = [&]() {
+      if (h->opts.keep_schur) return;
+      ch1.close();
+      ch2.close();
+      hs_hss_free((hs_hss*)c1.S_hss);
+      hs_hss_free((hs_hss*)c2.S_hss);
+      c1.S_hss = c2.S_hss = nullptr;
+    };
+    if (x.nb == 0) {
+      release_children();
+      continue;
+    }
+    // ---- Aib = C_R*Z_R and Abi = C_L*Z_L from the children's generators + the sparse couplings (nothing is recompressed) -------------------
+    std::vector<HsFillEntry> fcR, fzR, fcL, fzL;
+    const int oR1 = 0, oR2 = ch1.r12, oRx = ch1.r12 + ch2.r12;
+    const int rR = oRx + mf_factor_coupling(x.xr, oRx, fcR, fzR);
+    const int oL1 = 0, oL2 = ch1.r21, oLx = ch1.r21 + ch2.r21;
+    const int rL = oLx + mf_factor_coupling(x.xl, oLx, fcL, fzL);
+    (void)oR1; (void)oL1;
+    LowRank<T>* lrL = new LowRank<T>();
+    LowRank<T>* lrR = new LowRank<T>();
+    x.lrL = lrL;
+    x.lrR = lrR;
+    lrL->rows = x.nb; lrL->cols = x.ni; lrL->r = rL; lrL->k = rL;
+    lrR->rows = x.ni; lrR->cols = x.nb; lrR->r = rR; lrR->k = rR;
+    lrL->ldc = rup(std::max(x.nb, 1), 2); lrL->ldz = rup(std::max(rL, 1), 2);
+    lrR->ldc = rup(std::max(x.ni, 1), 2); lrR->ldz = rup(std::max(rR, 1), 2);
+    auto zalloc = [&](T** p, size_t elems, const char* what) {
+      dmalloc((void**)p, (elems + 32) * sizeof(T), what);
+      HS_HIP(hipMemsetAsync(*p, 0, (elems + 32) * sizeof(T), s));
+    };
+    zalloc(&lrL->Cd, (size_t)lrL->ldc * std::max(rL, 1), "C_L");
+    zalloc(&lrL->Z, (size_t)lrL->ldz * std::max(x.ni, 1), "Z_L");
+    zalloc(&lrR->Cd, (size_t)lrR->ldc * std::max(rR, 1), "C_R");
+    zalloc(&lrR->Z, (size_t)lrR->ldz * std::max(x.nb, 1), "Z_R");
+    auto offd = [&](MfChild& c, int which, T* Cp, int ldc, T* Zp, int ldz) {
+      if (c.n1 == 0 || c.n2 == 0) return;
+      mf_check(hs_hss_set_stream(c.S, (void*)s));
+      mf_check(hs_hss_offdiag(c.S, which, (double*)Cp, ldc, (double*)Zp, ldz, 1));
+    };
+    // Aib: rows int, columns bnd;  block (1,1) = A12 of S1, block (2,2) = A12 of S2
+    offd(ch1, 0, lrR->Cd, lrR->ldc, lrR->Z, lrR->ldz);
+    offd(ch2, 0, lrR->Cd + ch1.n1 + (size_t)oR2 * lrR->ldc, lrR->ldc, lrR->Z + oR2 + (size_t)ch1.n2 * lrR->ldz, lrR->ldz);
+    // Abi: rows bnd, columns int;  block (1,1) = A21 of S1, block (2,2) = A21 of S2
+    offd(ch1, 1, lrL->Cd, lrL->ldc, lrL->Z, lrL->ldz);
+    offd(ch2, 1, lrL->Cd + ch1.n2 + (size_t)oL2 * lrL->ldc, lrL->ldc, lrL->Z + oL2 + (size_t)ch1.n1 * lrL->ldz, lrL->ldz);
+    mf_fill<T>(h, fcR, lrR->Cd, lrR->ldc, buf);
+    mf_fill<T>(h, fzR, lrR->Z, lrR->ldz, buf);
+    mf_fill<T>(h, fcL, lrL->Cd, lrL->ldc, buf);
+    mf_fill<T>(h, fzL, lrL->Z, lrL->ldz, buf);
+    x.last_rL = rL;
+    x.last_rR = rR;
+    h->maxrank = std::max<int64_t>(h->maxrank, std::max(rL, rR));
+    if (say)
+      fprintf(stderr, "[hs] node %d (level %d, ni=%d, nb=%d): rank(L)=%d (%d+%d from the children, %d sparse) rank(R)=%d (%d+%d, %d sparse)\n", id, x.level, x.ni,
+              x.nb, rL, ch1.r21, ch2.r21, rL - oLx, rR, ch1.r12, ch2.r12, rR - oRx);
+    lap("Aib, Abi from the generators");
+    // ---- W = Aii^-1 * C_R (the R transform; C_R itself is not needed again) ---------------------------------------------------------------------
+    T* Mm = nullptr;
+    int ldm = 2;
+    if (rR > 0) {
+      mf_check(hs_hss_set_stream((hs_hss*)x.hss, (void*)s));
+      mf_check(hs_hss_ldiv((hs_hss*)x.hss, (double*)lrR->Cd, lrR->ldc, rR, 1));
+      x.hW = lrR->Cd;  // ownership moves to the node (freed with the HSS objects); the low-rank object keeps only Z_R
+      x.hldw = lrR->ldc;
+      lrR->Cd = nullptr;
+      lap("W = D^-1 C_R");
+      if (rL > 0) {  // M = Z_L * W  (rL x rR):  Abi*R = C_L * M * Z_R
+        ldm = rup(rL, 2);
+        Mm = buf.get((size_t)ldm * rR, "Z_L*W");
+        HS_HIP(hipMemsetAsync(Mm, 0, sizeof(T) * (size_t)ldm * rR, s));
+        GemmProb<T> gp{lrL->Z, (const T*)x.hW, Mm, rL, rR, x.ni, lrL->ldz, x.hldw, ldm};
+        GemmProb<T>* dgp = (GemmProb<T>*)buf.get((sizeof(GemmProb<T>) + sizeof(T) - 1) / sizeof(T), "GEMM descriptor");
+        HS_HIP(hipMemcpyAsync(dgp, &gp, sizeof gp, hipMemcpyHostToDevice, s));
+        HS_HIP(hipStreamSynchronize(s));
+        launch_gemm_probs<T>(dgp, 1, rL, rR, 0, s);
+      }
+    }
+    const bool upd = rL > 0 && rR > 0;
+    // ---- S = P (Abb - Abi*R) P' from products and entries of the operator [S1.A22 A[bnd1,bnd2]; A[bnd2,bnd1] S2.A22] - C_L*M*Z_R ----------
+    hs_hss_blockop opb{ch1.n2, ch2.n2, ch1.a22, ch2.a22, gid.data() + x.ni, &As, (int32_t*)h->d_lpos};
+    if (x.s_hss) {
+      const int64_t fs = (x.n1p > 0 && x.n1p < x.nb) ? x.n1p : 0;
+      hs_hss_options o = mf_options(h, id, 1.0, fs, x.last_ks, x.nb);
+      hs_hss* Sh = nullptr;
+      mf_check(h->is_complex ? hs_hss_compress_blockop_z(&opb, (const double*)lrL->Cd, lrL->ldc, (const double*)Mm, ldm, (const double*)lrR->Z, lrR->ldz, upd ? rL : 0,
+                                                         upd ? rR : 0, x.sperm.data(), &o, s, &Sh)
+                             : hs_hss_compress_blockop_d(&opb, (const double*)lrL->Cd, lrL->ldc, (const double*)Mm, ldm, (const double*)lrR->Z, lrR->ldz, upd ? rL : 0,
+                                                         upd ? rR : 0, x.sperm.data(), &o, s, &Sh));
+      x.S_hss = Sh;
+      x.last_ks = (int)hs_hss_samples(Sh);
+      h->maxrank = std::max<int64_t>(h->maxrank, hs_hss_rank(Sh));
+      if (say) fprintf(stderr, "[hs] node %d (level %d, nb=%d): hssrank(S)=%lld (%lld samples), matrix-free\n", id, x.level, x.nb, (long long)hs_hss_rank(Sh), (long long)hs_hss_samples(Sh));
+      lap("S: compress(Abb - Abi R) matrix-free");
+    } else {
+      // the parent assembles a dense front: S is formed by applying the operator to the identity, a block of columns at a time
+      T* SB = x.ext_sb ? (T*)x.ext_sb : (T*)h->d_sb + x.off_SB;
+      const int cb = 1024, ldi = rup(x.nb, 2);
+      T* I_ = buf.get((size_t)ldi * cb, "identity block");
+      T* t1 = upd ? buf.get((size_t)ldm * cb, "M*Z_R block") : nullptr;
+      GemmProb<T>* dgp = (GemmProb<T>*)buf.get((2 * sizeof(GemmProb<T>) + sizeof(T) - 1) / sizeof(T), "GEMM descriptors");
+      for (int c0 = 0; c0 < x.nb; c0 += cb) {
+        const int nc = std::min(cb, x.nb - c0);
+        launch_identity_cols<T>(I_, ldi, x.nb, c0, nc, s);
+        mf_check(hs_hss_blockop_apply(&opb, h->is_complex, (const double*)I_, ldi, (double*)(SB + (size_t)c0 * x.lds), x.lds, nc, 0, s));
+        if (upd) {
+          HS_HIP(hipMemsetAsync(t1, 0, sizeof(T) * (size_t)ldm * nc, s));
+          GemmProb<T> gp[2] = {GemmProb<T>{Mm, lrR->Z + (size_t)c0 * lrR->ldz, t1, rL, nc, rR, ldm, lrR->ldz, ldm},
+                               GemmProb<T>{lrL->Cd, t1, SB + (size_t)c0 * x.lds, x.nb, nc, rL, lrL->ldc, ldm, x.lds}};
+          HS_HIP(hipMemcpyAsync(dgp, gp, sizeof gp, hipMemcpyHostToDevice, s));
+          HS_HIP(hipStreamSynchronize(s));
+          launch_gemm_probs<T>(dgp, 1, rL, nc, 0, s);
+          launch_gemm_probs<T>(dgp + 1, 1, x.nb, nc, 1, s);
+        }
+      }
+      lap("S: formed densely for a dense parent");
+    }
+    HS_HIP(hipStreamSynchronize(s));
+    release_children();
+  }
+}

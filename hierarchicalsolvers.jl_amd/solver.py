@@ -31,7 +31,7 @@ class SolverOptions:
     ``5, 1, 1e-6, 1e-6, 0.5, 32, -1, 10, false`` (HierarchicalSolvers.jl:43-54)."""
 
     _fields = ("swlevel", "swsize", "atol", "rtol", "c_tol", "leafsize", "kest", "stepsize", "verbose")
-    _ext = ("keep_schur", "seed", "profile", "split_size", "hss_min", "hss_dexp")
+    _ext = ("keep_schur", "seed", "profile", "split_size", "hss_min", "hss_dexp", "mf")
 
     def __init__(self, **kw):
         self.swlevel, self.swsize = 5, 1
@@ -44,6 +44,7 @@ class SolverOptions:
         self.split_size = 0  # columns per slice of a compressed front's interior block (multiple of 256, 0 = off)
         self.hss_min = 0  # > 0 (multiple of 1024): compressed-level fronts with at least this many interior DOFs keep D as HSS
         self.hss_dexp = None  # orders of magnitude by which the HSS form of D is tighter than atol, rtol (None: 2; 0: the same)
+        self.mf = False  # matrix-free compressed branch: S leaves flagged fronts as HSS, parents assemble from the children's generators
         self._set(kw)
 
     def _set(self, kw):
@@ -77,6 +78,7 @@ class SolverOptions:
         if hm < 0 or hm % 1024 or hm // 1024 > 255:
             raise ValueError("hss_min must be a multiple of 1024 in 0:261120")
         o.hss_d = hm // 1024
+        o.mf = 1 if self.mf else 0
         if self.hss_dexp is not None:
             if not 0 <= int(self.hss_dexp) <= 12:
                 raise ValueError("hss_dexp must be in 0:12")

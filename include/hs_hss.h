@@ -72,6 +72,7 @@ int hs_hss_set_stream(hs_hss* H, void* stream);
 int64_t hs_hss_rank(const hs_hss* H);      /* hssrank: largest rank of an off-diagonal block */
 int64_t hs_hss_size(const hs_hss* H);      /* n */
 int64_t hs_hss_samples(const hs_hss* H);   /* samples per side the adaptive compression ended with */
+int64_t hs_hss_bytes(const hs_hss* H);     /* device bytes held by the generators and, once eliminated, the factors (views: 0) */
 int64_t hs_hss_num_nodes(const hs_hss* H); /* nodes of the cluster tree (breadth-first numbering) */
 /* out[0..7] = lo, hi (0-based half-open index range), left, right (-1: leaf), level, m (local size), r (rank), isleaf */
 int hs_hss_node_info(const hs_hss* H, int64_t node, int64_t out[8]);
