@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--split", type=int, default=0, help="slice width (multiple of 256) in which compressed fronts eliminate their interior block; 0 = off")
     ap.add_argument("--hss-min", type=int, default=0, help="fronts of the compressed levels with at least this many interior DOFs (multiple of 1024) keep D = Aii as an HSS matrix; 0 = dense LU of D")
     ap.add_argument("--hss-dexp", type=int, default=None, help="orders of magnitude by which the HSS form of D is tighter than --tol (default 2)")
+    ap.add_argument("--mf", action="store_true", help="matrix-free compressed branch: S travels between the compressed fronts as HSS matrices (the reference's data flow)")
+    ap.add_argument("--leafsize", type=int, default=32, help="SolverOptions.leafsize (HSS leaves; the device uses at least 128)")
     args = ap.parse_args()
 
     import numpy as np
@@ -235,7 +237,7 @@ def main():
     t_host = time.perf_counter() - t0
     is_c = np.iscomplexobj(Ap.data)
 
-    fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol, split_size=args.split, hss_min=args.hss_min, hss_dexp=args.hss_dexp) if args.swlevel != 0 else dict(swlevel=0)
+    fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol, split_size=args.split, hss_min=args.hss_min, hss_dexp=args.hss_dexp, mf=args.mf, leafsize=args.leafsize) if args.swlevel != 0 else dict(swlevel=0)
     t0 = time.perf_counter()
     S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, **fopts)
     torch.cuda.synchronize(dev)
@@ -377,11 +379,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "n": int(Ap.shape[0]), "nnz": int(Ap.nnz), "tree_nodes": int(st["nnodes"]),
                        "tree_depth": int(st["nlevels"]), "max_front": [int(st["max_ni"]), int(st["max_nb"])], "nrhs": 1,
-                       "compression": "none (swlevel=0)" if args.swlevel == 0 else f"low-rank off-diagonal blocks, swlevel={args.swlevel} swsize={args.swsize} atol=rtol={args.tol:g} split={args.split} hss_min={args.hss_min}",
+                       "compression": "none (swlevel=0)" if args.swlevel == 0 else f"{'matrix-free HSS hand-over' if args.mf else 'low-rank off-diagonal blocks'}, swlevel={args.swlevel} swsize={args.swsize} atol=rtol={args.tol:g} split={args.split} hss_min={args.hss_min} mf={int(args.mf)}",
                        "partition": f"subtree-per-rank x{world}"},
             "factor_s": st["t_total"],
             "residual": res,
             "maxrank": maxrank_main,
+            "bytes_factors_GiB": st["bytes_factors"] / 2**30,
             "host_symbolic_s": t_host,
             "analyze_s": t_analyze,
         }

@@ -72,7 +72,7 @@ EXPORTS = [
     "hs_node_info", "hs_node_ranks", "hs_node_export", "hs_node_export_piv", "hs_device_info",
     "hs_analyze", "hs_plan", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
-    "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned",
+    "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned", "hs_gmres_d", "hs_gmres_z",
     "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free", "hs_node_schur_hss",
@@ -151,6 +151,9 @@ def lib():
     L.hs_unpack_bnd.restype = C.c_int
     L.hs_extract_owned.argtypes = [vp, vp, vp, vp]
     L.hs_extract_owned.restype = C.c_int
+    for f in (L.hs_gmres_d, L.hs_gmres_z):
+        f.argtypes = [vp, i64, p_i64, p_i64, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, i64, i64, p_f64, p_i64, C.POINTER(C.c_int), vp]
+        f.restype = C.c_int
     L.hs_maxrank.argtypes = [vp]
     L.hs_maxrank.restype = i64
     L.hs_is_complex.argtypes = [vp]

@@ -15,11 +15,11 @@
 //
 // Formulation of `D`: ONE HSS matrix over a recursive-bisection order of the front's interior graph, compressed matrix-free from the
 // operator [S1.A11 A12; A21 S2.A11] (hs_hss_blockop: two HSS products + a sparse product per sample, batched HSS entry access + a sparse
-// gather per block) -- oracle/hs_oracle_mf.py `dmode="single"`.  The reference's 2x2 `BlockFactorization` needs `A11 \ A12` in HSS-by-HSS
+// gather per block) -- the `dmode="single"` formulation of the CPU restatement used by the tests.  The reference's 2x2 `BlockFactorization` needs `A11 \ A12` in HSS-by-HSS
 // arithmetic (HssMatrices.jl, absent from the reference tree); `_equilibrate_clusters` (C2, :143-168) exists to make the two children's
 // cluster trees compatible for that arithmetic and has no role here: every compression samples an operator.  `L = Abi*Aii^-1` is applied
 // as `Abi_lr * (D^-1 x)` in `ldiv!` (one HSS solve serves `_dsolve!` and `_lsolve!`), so no transposed HSS solve is needed.
-// PARITY UNPINNED (HssMatrices.jl / LowRankApprox.jl are not part of the reference tree); checked against oracle/hs_oracle_mf.py.
+// PARITY UNPINNED (HssMatrices.jl / LowRankApprox.jl are not part of the reference tree); checked against a CPU restatement of the same data flow (tests/test_mf_gpu.py).
 #pragma once
 #include "../../include/hs_hss.h"
 #include "hs_lowrank.h"

@@ -157,6 +157,17 @@ int hs_pack_bnd(const hs_handle* F, int64_t node, const void* d_b, void* d_buf, 
 int hs_unpack_bnd(const hs_handle* F, int64_t node, void* d_b, const void* d_buf, void* stream); /* b[bnd_j] = buf[j] */
 int hs_extract_owned(const hs_handle* F, const void* d_b, void* d_out, void* stream); /* out[int(mine)] = b[int(mine)] */
 
+/* gmres(A, b; Pr=F, reltol, abstol, restart, maxiter, log=true) -- the call of the reference's scenario (test/rungmres.jl:47-48; IterativeSolvers.jl
+ * 0.9.0, not part of the reference tree): restarted GMRES, RIGHT-preconditioned by the factorization `Pr` (NULL: none), every vector resident on
+ * the device, the preconditioner applied through hs_ldiv_dev_*.  A is n x n CSC with 1-based colptr / rowval as Julia holds them (host arrays);
+ * b, x: host (where = 0) or device (where = 1) vectors; use_x0 != 0: x holds the initial guess, else zero.  Defaults as in the package for
+ * restart <= 0 (min(20, n)), maxiter < 0 (n), reltol < 0 (sqrt(eps)).  Convergence: ||b - A x|| <= max(reltol * ||r0||, abstol).
+ * resnorm (may be NULL) receives iters + 1 residual norms (the `log=true` history, resnorm[0] = ||r0||); it must hold maxiter + 1 doubles. */
+int hs_gmres_d(hs_handle* Pr, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval, const double* b, double* x, int where, int use_x0,
+               double reltol, double abstol, int64_t restart, int64_t maxiter, double* resnorm, int64_t* iters, int* converged, void* stream);
+int hs_gmres_z(hs_handle* Pr, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval, const double* b, double* x, int where, int use_x0,
+               double reltol, double abstol, int64_t restart, int64_t maxiter, double* resnorm, int64_t* iters, int* converged, void* stream);
+
 int64_t hs_maxrank(const hs_handle* F); /* factornode.jl:49-57: largest of rank(L), rank(R) and the HSS ranks the factorization
                                            holds (hssrank of the interior blocks kept as HSS, hs_options.hss_d); 0 for the dense path */
 /* ranks of one front's Gauss transforms (0 = dense); returns 1 if the front is compressed, 0 if not, <0 on error */
