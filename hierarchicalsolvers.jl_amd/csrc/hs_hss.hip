@@ -51,6 +51,9 @@ __global__ __launch_bounds__(256) void hss_randn_kernel(double* out, int rows_d,
   out[(size_t)r + (size_t)c * ld_d] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
 }
 
+__device__ inline double conj_of(double a) { return a; }
+__device__ inline cplx conj_of(cplx a) { return {a.re, -a.im}; }
+
 enum { ROW_GATHER = 0, ROW_GATHER_NEG = 1, ROW_SCATTER = 2, ROW_SCATTER_ADD = 3 };
 template <class T>
 struct RowJob {
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(64) void sub_gather_kernel(const SubJob<T>* __restr
   const size_t ar = (size_t)j.r0 + (j.ri ? j.ri[i] : i);
   for (int c = c0; c < c1; ++c) {
     const size_t ac = (size_t)j.c0 + (j.ci ? j.ci[c] : c);
-    const T v = j.A[ar + ac * j.lda];
+    T v = j.A[ar + ac * j.lda];
+    if (j.trans == 2) v = conj_of(v);  // conjugate transpose (the orthonormal bases of the QR refinement)
     if (j.trans)
       j.out[(size_t)c + (size_t)i * j.ldo] = v;
     else
@@ -402,6 +406,264 @@ struct Lru {
 // ------------------------------------------------------------------------------------------------
 // compression with k samples per side; returns false when some rank came too close to k (caller doubles k)
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Rank and interpolation matrix of a row ID from an orthogonalisation of the rows in PIVOT ORDER ("QR in the order a tournament-pivoted
+// LU chose": the pivot rows of the LU are as good a skeleton as a column-pivoted QR's, but |u_jj| overestimates the residual norm
+// |R_jj| by the growth of the elimination and T = L21*L11^-1 interpolates a few sketch columns exactly instead of all of them in the
+// least-squares sense -- measured: ranks 1.4-2x a pivoted QR's, and at the upper levels of a nested compression the children's
+// truncation noise, sitting just below the threshold, was counted as rank).
+//
+// Block classical Gram-Schmidt with re-orthogonalisation over blocks of 32 rows, every block finished by a Cholesky-QR of the 32
+// residual rows (one wave per block): M[p, :] = L * Q with orthonormal rows of Q; d_j = L_jj is the distance of row j from the span of
+// the rows before it -- the |R_jj| of the pivoted QR of M^H in that order.  Rank = rows with d_j > tau; the remaining rows are
+// interpolated in the least-squares sense: M[p_R, :] ~= (M[p_R, :] Q_S^H) Q_S = T * M[p_S, :] with T = L_RS * L_SS^-1.
+// Everything heavy is a grouped MFMA GEMM over the blocks of a tree level; the role of `pqrfact` (rank-revealing QR, tolerance-stopped)
+// inside the HSS compression of the reference (src/factorization.jl:110).
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct CholJob {
+  T* G;          // b x b Gram matrix of the residual rows (ld 32), destroyed
+  T* Lout;       // -> L[I, I] (ld ldl)
+  int ldl;
+  T* Linv;       // b x b inverse of the Cholesky factor (ld 32)
+  double* d;     // b diagonal entries
+  double* top;   // in/out: d_0 of the job (written by the first block)
+  int b, first;
+};
+template <class T>
+__device__ inline double real_of(T a);
+template <>
+__device__ inline double real_of<double>(double a) { return a; }
+template <>
+__device__ inline double real_of<cplx>(cplx a) { return a.re; }
+template <class T>
+__device__ inline T from_real(double a);
+template <>
+__device__ inline double from_real<double>(double a) { return a; }
+template <>
+__device__ inline cplx from_real<cplx>(double a) { return {a, 0.0}; }
+
+template <class T>
+__global__ __launch_bounds__(64) void chol_block_kernel(const CholJob<T>* __restrict__ jobs) {
+  const CholJob<T> j = jobs[blockIdx.x];
+  __shared__ T g[32][33];
+  __shared__ T li[32][33];
+  const int t = threadIdx.x, b = j.b;
+  if (t < 32)
+    for (int c = 0; c < 32; ++c) g[t][c] = (t < b && c < b) ? j.G[(size_t)t + (size_t)c * 32] : Scal<T>::zero();
+  __syncthreads();
+  double top = j.first ? sqrt(fmax(real_of(g[0][0]), 0.0)) : *j.top;
+  const double floor2 = top * top * 1e-30 + 1e-300;
+  for (int k = 0; k < b; ++k) {
+    const double dk = sqrt(fmax(real_of(g[k][k]), floor2));
+    __syncthreads();
+    if (t < b && t >= k) g[t][k] = t == k ? from_real<T>(dk) : g[t][k] / from_real<T>(dk);
+    __syncthreads();
+    if (t < b && t > k)
+      for (int c = k + 1; c <= t; ++c) g[t][c] = Scal<T>::fnma(g[t][k], conj_of(g[c][k]), g[t][c]);  // lower triangle only
+    __syncthreads();
+  }
+  // inverse of the lower-triangular factor: thread c solves L x = e_c
+  if (t < b) {
+    for (int i = 0; i < b; ++i) li[i][t] = Scal<T>::zero();
+    li[t][t] = Scal<T>::one() / g[t][t];
+    for (int i = t + 1; i < b; ++i) {
+      T acc = Scal<T>::zero();
+      for (int k = t; k < i; ++k) acc = Scal<T>::fma(g[i][k], li[k][t], acc);
+      li[i][t] = (Scal<T>::zero() - acc) / g[i][i];
+    }
+  }
+  __syncthreads();
+  if (t < 32)
+    for (int c = 0; c < 32; ++c) {
+      if (t < b && c < b) {
+        j.Lout[(size_t)t + (size_t)c * j.ldl] = c <= t ? g[t][c] : Scal<T>::zero();
+        j.Linv[(size_t)t + (size_t)c * 32] = li[t][c];
+      } else {
+        j.Linv[(size_t)t + (size_t)c * 32] = Scal<T>::zero();
+      }
+    }
+  if (t < b) j.d[t] = real_of(g[t][t]);
+  if (t == 0 && j.first) *j.top = top;
+}
+
+template <class T>
+struct QrJob {
+  const T* M;     // m x q block whose rows are interpolated (ld ldm), left untouched
+  int ldm, m, q;
+  const int* p;   // device: pivot order of the rows (m entries)
+  int rmax;       // rows worth orthogonalising: the rank the pivoted LU reported (an upper bound)
+  // results
+  int r = 0;
+  double top = 0.0;      // d_0
+  T* Tm = nullptr;       // (m - r) x r, ld ldt, allocated from `out_pool` by qr_refine
+  int ldt = 2;
+};
+
+// atol / rtol: rank = number of leading rows with d_j > max(atol, rtol * max(d_0, scale_floor))
+template <class T>
+void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double atol, double rtol, double scale_floor, hipStream_t s) {
+  const int nj = (int)jobs.size();
+  if (nj == 0) return;
+  struct St {
+    T *Q = nullptr, *Qh = nullptr, *L = nullptr, *Linv = nullptr, *W = nullptr, *Wh = nullptr, *C1 = nullptr, *C2 = nullptr, *G = nullptr;
+    double *d = nullptr, *top = nullptr;
+    int ldq = 2, ldqh = 2, ldl = 2, done = 0, active = 1, nblk = 0;
+    std::vector<double> hd;
+  };
+  std::vector<St> st(nj);
+  int maxsteps = 0;
+  for (int a = 0; a < nj; ++a) {
+    QrJob<T>& J = jobs[a];
+    St& S = st[a];
+    J.rmax = std::max(0, std::min(J.rmax, std::min(J.m, J.q)));
+    J.r = 0;
+    if (J.rmax == 0) {
+      S.active = 0;
+      continue;
+    }
+    S.nblk = (J.rmax + 31) / 32;
+    maxsteps = std::max(maxsteps, S.nblk);
+    S.ldq = ev(J.rmax);
+    S.ldqh = ev(J.q);
+    S.ldl = ev(J.rmax);
+    S.Q = tmp.get<T>((size_t)S.ldq * J.q);
+    S.Qh = tmp.get<T>((size_t)S.ldqh * J.rmax);
+    S.L = tmp.get<T>((size_t)S.ldl * J.rmax);
+    S.Linv = tmp.get<T>((size_t)S.nblk * 1024);
+    S.W = tmp.get<T>((size_t)32 * J.q);
+    S.Wh = tmp.get<T>((size_t)S.ldqh * 32);
+    S.C1 = tmp.get<T>((size_t)32 * J.rmax);
+    S.C2 = tmp.get<T>((size_t)32 * J.rmax);
+    S.G = tmp.get<T>(1024);
+    S.d = tmp.get<double>((size_t)J.rmax + 32);
+    S.top = tmp.get<double>(4);
+    HSS_HIP(hipMemsetAsync(S.L, 0, sizeof(T) * (size_t)S.ldl * J.rmax, s));
+    S.hd.assign((size_t)J.rmax + 32, 0.0);
+  }
+  std::vector<RowJob<T>> rows;
+  std::vector<SubJob<T>> subs;
+  std::vector<GemmProb<T>> g;
+  for (int step = 0; step < maxsteps; ++step) {
+    const int r0 = 32 * step;
+    auto each = [&](auto&& f) {
+      for (int a = 0; a < nj; ++a)
+        if (st[a].active && step < st[a].nblk) f(jobs[a], st[a], std::min(32, jobs[a].rmax - r0));
+    };
+    // W = M[p[r0 : r0+b], :]
+    each([&](QrJob<T>& J, St& S, int b) { rows.push_back(RowJob<T>{J.M, J.ldm, S.W, 32, J.p + r0, b, J.q, ROW_GATHER}); });
+    if (rows.empty()) break;
+    run_rows(tmp, rows, s);
+    if (r0 > 0) {
+      for (int pass = 0; pass < 2; ++pass) {  // classical Gram-Schmidt, twice
+        each([&](QrJob<T>& J, St& S, int b) {
+          T* Cx = pass == 0 ? S.C1 : S.C2;
+          HSS_HIP(hipMemsetAsync(Cx, 0, sizeof(T) * (size_t)32 * r0, s));
+          g.push_back(GemmProb<T>{S.W, S.Qh, Cx, b, r0, J.q, 32, S.ldqh, 32});
+        });
+        run_gemms(tmp, g, 0, s);
+        each([&](QrJob<T>& J, St& S, int b) { g.push_back(GemmProb<T>{pass == 0 ? S.C1 : S.C2, S.Q, S.W, b, J.q, r0, 32, S.ldq, 32}); });
+        run_gemms(tmp, g, 1, s);
+      }
+      // L[I, :r0] = C1 + C2
+      each([&](QrJob<T>& J, St& S, int b) {
+        rows.push_back(RowJob<T>{S.C1, 32, S.L + r0, S.ldl, nullptr, b, r0, ROW_GATHER});
+        (void)J;
+      });
+      run_rows(tmp, rows, s);
+      each([&](QrJob<T>& J, St& S, int b) {
+        rows.push_back(RowJob<T>{S.C2, 32, S.L + r0, S.ldl, nullptr, b, r0, ROW_SCATTER_ADD});
+        (void)J;
+      });
+      run_rows(tmp, rows, s);
+    }
+    // G = W * W^H, Cholesky-QR of the block
+    each([&](QrJob<T>& J, St& S, int b) { subs.push_back(SubJob<T>{S.W, 32, nullptr, nullptr, 0, 0, b, J.q, S.Wh, S.ldqh, 2}); });
+    run_subs(tmp, subs, s);
+    std::vector<CholJob<T>> cj;
+    each([&](QrJob<T>& J, St& S, int b) {
+      HSS_HIP(hipMemsetAsync(S.G, 0, sizeof(T) * 1024, s));
+      g.push_back(GemmProb<T>{S.W, S.Wh, S.G, b, b, J.q, 32, S.ldqh, 32});
+      cj.push_back(CholJob<T>{S.G, S.L + r0 + (size_t)r0 * S.ldl, S.ldl, S.Linv + (size_t)step * 1024, S.d + r0, S.top, b, step == 0 ? 1 : 0});
+    });
+    run_gemms(tmp, g, 0, s);
+    CholJob<T>* dcj = upload(tmp, cj);
+    hipLaunchKernelGGL(chol_block_kernel<T>, dim3((unsigned)cj.size()), dim3(64), 0, s, (const CholJob<T>*)dcj);
+    // Q[I, :] = Linv * W, Qh[:, I] = Q[I, :]^H
+    each([&](QrJob<T>& J, St& S, int b) {
+      HSS_HIP(hipMemset2DAsync(S.Q + r0, sizeof(T) * S.ldq, 0, sizeof(T) * b, J.q, s));
+      g.push_back(GemmProb<T>{S.Linv + (size_t)step * 1024, S.W, S.Q + r0, b, J.q, b, 32, 32, S.ldq});
+    });
+    run_gemms(tmp, g, 0, s);
+    each([&](QrJob<T>& J, St& S, int b) { subs.push_back(SubJob<T>{S.Q + r0, S.ldq, nullptr, nullptr, 0, 0, b, J.q, S.Qh + (size_t)r0 * S.ldqh, S.ldqh, 2}); });
+    run_subs(tmp, subs, s);
+    // the block's diagonal: decide which jobs go on
+    each([&](QrJob<T>& J, St& S, int b) {
+      HSS_HIP(hipMemcpyAsync(S.hd.data() + r0, S.d + r0, sizeof(double) * b, hipMemcpyDeviceToHost, s));
+      (void)J;
+    });
+    HSS_HIP(hipStreamSynchronize(s));
+    each([&](QrJob<T>& J, St& S, int b) {
+      if (step == 0) J.top = S.hd[0];
+      const double tau = std::max(atol, rtol * std::max(J.top, scale_floor));
+      S.done = r0 + b;
+      bool any = false;
+      for (int i = 0; i < b; ++i) any = any || S.hd[(size_t)r0 + i] > tau;
+      if (!any) S.active = 0;  // a whole block below the threshold: the rank has been passed
+    });
+  }
+  // ranks
+  int maxR = 0, maxr = 0;
+  for (int a = 0; a < nj; ++a) {
+    QrJob<T>& J = jobs[a];
+    St& S = st[a];
+    const double tau = std::max(atol, rtol * std::max(J.top, scale_floor));
+    int r = 0;
+    for (int i = 0; i < S.done; ++i)
+      if (S.hd[(size_t)i] > tau) r = i + 1;
+    J.r = r;
+    J.ldt = ev(J.m - r);
+    J.Tm = out_pool.get<T>((size_t)J.ldt * std::max(r, 1));
+    maxR = std::max(maxR, J.m - r);
+    maxr = std::max(maxr, r);
+  }
+  // T = (M[p_R, :] * Q_S^H) * L_SS^-1, column blocks of 32 from the right
+  std::vector<T*> YR(nj, nullptr), T2(nj, nullptr);
+  for (int a = 0; a < nj; ++a) {
+    QrJob<T>& J = jobs[a];
+    St& S = st[a];
+    const int nR = J.m - J.r;
+    if (nR <= 0 || J.r <= 0) continue;
+    YR[a] = tmp.get<T>((size_t)ev(nR) * J.q);
+    T2[a] = tmp.get<T>((size_t)ev(nR) * 32);
+    rows.push_back(RowJob<T>{J.M, J.ldm, YR[a], ev(nR), J.p + J.r, nR, J.q, ROW_GATHER});
+    HSS_HIP(hipMemsetAsync(J.Tm, 0, sizeof(T) * (size_t)J.ldt * J.r, s));
+    g.push_back(GemmProb<T>{YR[a], S.Qh, J.Tm, nR, J.r, J.q, ev(nR), S.ldqh, J.ldt});
+  }
+  run_rows(tmp, rows, s);
+  run_gemms(tmp, g, 0, s);  // Tm <- L_RS
+  for (int j0 = (maxr - 1) / 32 * 32; j0 >= 0; j0 -= 32) {
+    std::vector<GemmProb<T>> g1, g2;
+    std::vector<SubJob<T>> back;
+    for (int a = 0; a < nj; ++a) {
+      QrJob<T>& J = jobs[a];
+      St& S = st[a];
+      const int nR = J.m - J.r, r = J.r;
+      if (nR <= 0 || r <= j0) continue;
+      const int j1 = std::min(j0 + 32, r), w = j1 - j0;
+      if (r > j1) g1.push_back(GemmProb<T>{J.Tm + (size_t)j1 * J.ldt, S.L + j1 + (size_t)j0 * S.ldl, J.Tm + (size_t)j0 * J.ldt, nR, w, r - j1, J.ldt, S.ldl, J.ldt});
+      // the leading w x w part of the block's inverse is the inverse of the leading part of its factor (lower triangular)
+      HSS_HIP(hipMemsetAsync(T2[a], 0, sizeof(T) * (size_t)ev(nR) * 32, s));
+      g2.push_back(GemmProb<T>{J.Tm + (size_t)j0 * J.ldt, S.Linv + (size_t)(j0 / 32) * 1024, T2[a], nR, w, w, J.ldt, 32, ev(nR)});
+      back.push_back(SubJob<T>{T2[a], ev(nR), nullptr, nullptr, 0, 0, nR, w, J.Tm + (size_t)j0 * J.ldt, J.ldt, 0});
+    }
+    run_gemms(tmp, g1, 1, s);
+    run_gemms(tmp, g2, 0, s);
+    run_subs(tmp, back, s);
+  }
+  HSS_HIP(hipStreamSynchronize(s));
+}
+
 template <class T>
 struct BlockOp;  // hs_hss_op.h: [H1 A12; A21 H2] of two HSS blocks and sparse couplings, never formed
 template <class T>
@@ -539,6 +801,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       ldl[i] = ldn;
     }
   double gscale = 0.0;  // largest sample pivot seen so far (deeper levels): the scale of the matrix's off-diagonal part
+  double gscale_q = 0.0;  // the same in terms of the row norms of the orthogonalisation (qr_refine)
   for (int lv = H.nlev - 1; lv >= 1; --lv) {
     const std::vector<int>& L = H.lev[lv];
     const int nj = (int)L.size();
@@ -605,11 +868,32 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       free_lr();
       throw st;
     }
-    // ---- c. skeletons, interpolation matrices ----------------------------------------------------------------------------
+    // ---- c. skeletons, interpolation matrices: rank and least-squares T from the orthogonalisation of the rows in pivot order -------
+    static const bool qr_on = !(getenv("HS_HSS_QR") && getenv("HS_HSS_QR")[0] == '0');  // diagnostics: 0 = the LU-based rule and T = L21*L11^-1
+    std::vector<QrJob<T>> qj;
+    if (qr_on) {
+      qj.resize(nj);
+      for (int a = 0; a < nj; ++a) {
+        const int i = L[a];
+        qj[a].M = Yl[i];
+        qj[a].ldm = ldl[i];
+        qj[a].m = nd[i].m;
+        qj[a].q = k2;
+        qj[a].p = lr[a].rperm;
+        qj[a].rmax = lr[a].k;  // the pivoted LU ordered the first k (sketch width) rows; the orthogonalisation stops by itself once a block of 32 rows is below the threshold
+      }
+      try {
+        qr_refine<T>(tmp, H.keep, qj, std::max(H.opt.atol, H.opt.rtol * gscale_q) * lsc, H.opt.rtol * lsc, 0.0, s);
+      } catch (...) {
+        free_lr();
+        throw;
+      }
+      for (int a = 0; a < nj; ++a) gscale_q = std::max(gscale_q, qj[a].top);
+    }
     bool enough = true;
     for (int a = 0; a < nj; ++a) {
       const int m = nd[L[a]].m;
-      int r = lr[a].r;
+      int r = qr_on ? qj[a].r : lr[a].r;
       if (r < 1 && m > 0) r = 1;  // keep one skeleton position: every later shape stays non-empty
       // a sketch of k samples is trusted up to rank 0.8*k - pad: the spectra of separator blocks decay slowly, and a rank within a few
       // per cent of k means the tail beyond the sketch was never seen (measured on the 32,768 root of Poisson 128^3: rank 2,016 of 2,048
@@ -619,16 +903,18 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     }
     static const bool verbose = getenv("HS_HSS_VERBOSE") != nullptr;
     if (verbose) {
-      int mr = 0, mm = 0, full = 0;
+      int mr = 0, mm = 0, full = 0, mlu = 0;
       long long sr = 0;
-      for (int i : L) {
+      for (int a = 0; a < nj; ++a) {
+        const int i = L[a];
         mr = std::max(mr, nd[i].r);
         mm = std::max(mm, nd[i].m);
+        mlu = std::max(mlu, lr[a].r);
         sr += nd[i].r;
         full += nd[i].r == nd[i].m;
       }
-      fprintf(stderr, "[hs hss] n=%d k=%d level %d: %d nodes, local size <= %d, rank max %d mean %.1f, %d nodes of full rank%s\n", n, k, lv, nj, mm, mr,
-              (double)sr / nj, full, enough ? "" : "  -> more samples");
+      fprintf(stderr, "[hs hss] n=%d k=%d level %d: %d nodes, local size <= %d, rank max %d mean %.1f (pivoted-LU estimate <= %d), %d nodes of full rank%s\n", n, k, lv,
+              nj, mm, mr, (double)sr / nj, mlu, full, enough ? "" : "  -> more samples");
     }
     if (!enough) {
       HSS_HIP(hipStreamSynchronize(s));
@@ -647,18 +933,22 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
         x.sk = H.keep.template get<int>(r);
         x.ldt = ev(nR);
         x.ldtt = ev(r);
-        x.Tm = H.keep.template get<T>((size_t)x.ldt * r);
         x.Tt = H.keep.template get<T>((size_t)x.ldtt * std::max(nR, 1));
-        if (lr[a].r >= 1)
-          subs.push_back(SubJob<T>{lr[a].Lp, lr[a].ldp, nullptr, nullptr, r, 0, nR, r, x.Tm, x.ldt, 0});  // T <- L21
-        else  // the sample block is zero (the node does not couple to the rest at all): one nominal skeleton position, T = 0 --
-          HSS_HIP(hipMemsetAsync(x.Tm, 0, sizeof(T) * (size_t)x.ldt * r, s));  // the L\U of a zero sketch holds nothing usable
+        if (qr_on && qj[a].r >= 1) {
+          x.Tm = qj[a].Tm;  // least-squares interpolation from qr_refine (allocated from H.keep, ld = ev(nR))
+        } else {
+          x.Tm = H.keep.template get<T>((size_t)x.ldt * r);
+          if (!qr_on && lr[a].r >= 1)
+            subs.push_back(SubJob<T>{lr[a].Lp, lr[a].ldp, nullptr, nullptr, r, 0, nR, r, x.Tm, x.ldt, 0});  // T <- L21
+          else  // the sample block is zero (the node does not couple to the rest at all): one nominal skeleton position, T = 0 --
+            HSS_HIP(hipMemsetAsync(x.Tm, 0, sizeof(T) * (size_t)x.ldt * r, s));  // the L\U of a zero sketch holds nothing usable
+        }
         ij.push_back(IdxJob{x.p, (x.left < 0 && H.perm) ? H.perm + x.lo : Jidx[i], x.lo, r, x.sk});
         maxR = std::max(maxR, nR);
         maxr = std::max(maxr, r);
       }
       run_subs(tmp, subs, s);
-      if (maxR > 0) {
+      if (maxR > 0 && !qr_on) {
         // T = L21 * L11^-1, 32 columns at a time from the right; the descriptors of every step are uploaded once
         std::vector<GemmProb<T>> gp;
         std::vector<TsJob<T>> ts;
@@ -691,6 +981,8 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
           if (st.gn > 0) launch_gemm_probs<T>(dgp + st.g0, (int)st.gn, maxR, st.mN, 1, s);
           if (st.tn > 0) hipLaunchKernelGGL(tsolve_block_kernel<T>, dim3((maxR + 63) / 64, (unsigned)st.tn), dim3(64), 0, s, (const TsJob<T>*)(dts + st.t0));
         }
+      }
+      if (maxR > 0) {
         for (int a = 0; a < nj; ++a) {
           const HNode<T>& x = nd[L[a]];
           subs.push_back(SubJob<T>{x.Tm, x.ldt, nullptr, nullptr, 0, 0, x.m - x.r, x.r, x.Tt, x.ldtt, 1});  // T^T
