@@ -422,12 +422,17 @@ struct Lru {
 // ------------------------------------------------------------------------------------------------
 template <class T>
 struct CholJob {
-  T* G;          // b x b Gram matrix of the residual rows (ld 32), destroyed
-  T* Lout;       // -> L[I, I] (ld ldl)
+  T* G;          // b x b Gram matrix of the candidate rows (ld 32), destroyed
+  T* Lout;       // -> L[done : done+b', done : done+b'] (ld ldl)
   int ldl;
-  T* Linv;       // b x b inverse of the Cholesky factor (ld 32)
-  double* d;     // b diagonal entries
+  T* Linv;       // b' x b': inverse of the accepted Cholesky factor (ld 32) -- the triangular solves of the interpolation matrix
+  T* LinvP;      // b' x b : the same times the block's pivoting, Q_new = LinvP * W with W in candidate order (ld 32)
+  double* d;     // accepted diagonal entries (b' of them)
   double* top;   // in/out: d_0 of the job (written by the first block)
+  int* p;        // the job's candidate order at this window (b entries), permuted in place: accepted rows first
+  int* lperm;    // out: local order (b entries): new position i holds old candidate lperm[i]
+  int* nacc;     // out: b'
+  double atol, rtol, scale_floor;
   int b, first;
 };
 template <class T>
@@ -443,56 +448,119 @@ __device__ inline double from_real<double>(double a) { return a; }
 template <>
 __device__ inline cplx from_real<cplx>(double a) { return {a, 0.0}; }
 
+// Diagonally pivoted Cholesky of the Gram matrix of <= 32 candidate rows (one wave): the candidates are re-ordered by residual norm,
+// and only a well-conditioned prefix is ACCEPTED -- d_k above the truncation threshold and above 1e-5 of the block's first pivot (what a
+// Gram matrix resolves reliably in double precision is d_k / |w_k| >~ 1e-8).  Rejected candidates stay next in line: the following
+// window orthogonalises them against the rows accepted here before judging them again.
+#define HS_CHOL_COND 1e-5
 template <class T>
 __global__ __launch_bounds__(64) void chol_block_kernel(const CholJob<T>* __restrict__ jobs) {
   const CholJob<T> j = jobs[blockIdx.x];
   __shared__ T g[32][33];
   __shared__ T li[32][33];
+  __shared__ int perm[32];
+  __shared__ int s_piv;
+  __shared__ double s_dk;
+  __shared__ int s_nacc;
   const int t = threadIdx.x, b = j.b;
-  if (t < 32)
+  if (t < 32) {
     for (int c = 0; c < 32; ++c) g[t][c] = (t < b && c < b) ? j.G[(size_t)t + (size_t)c * 32] : Scal<T>::zero();
+    perm[t] = t;
+  }
+  if (t == 0) s_nacc = 0;
   __syncthreads();
-  double top = j.first ? sqrt(fmax(real_of(g[0][0]), 0.0)) : *j.top;
-  const double floor2 = top * top * 1e-30 + 1e-300;
+  double top = j.first ? 0.0 : *j.top, d0 = 0.0, tau = 0.0;
   for (int k = 0; k < b; ++k) {
-    const double dk = sqrt(fmax(real_of(g[k][k]), floor2));
+    if (t == 0) {  // largest remaining diagonal entry
+      int best = k;
+      double bv = real_of(g[k][k]);
+      for (int i = k + 1; i < b; ++i) {
+        const double v = real_of(g[i][i]);
+        if (v > bv) { bv = v; best = i; }
+      }
+      s_piv = best;
+      s_dk = bv > 0.0 ? sqrt(bv) : 0.0;
+    }
+    __syncthreads();
+    const int pv = s_piv;
+    const double dk = s_dk;
+    if (k == 0) {
+      d0 = dk;
+      if (j.first) top = dk;
+      tau = fmax(j.atol, j.rtol * fmax(top, j.scale_floor));
+    }
+    if (!(dk > tau) || !(dk > HS_CHOL_COND * d0) || !(dk > 0.0)) break;  // uniform: every thread sees the same dk
+    // symmetric swap k <-> pv of the (lower-triangle stored) matrix and of the finished columns
+    if (pv != k && t < b) {
+      if (t == 0) { const int q = perm[k]; perm[k] = perm[pv]; perm[pv] = q; }
+      // row/column swap on the full square copy: keep it simple, the matrix is 32 x 32 (both triangles are maintained)
+      const T a = g[t][k], c = g[t][pv];
+      g[t][k] = c;
+      g[t][pv] = a;
+    }
+    __syncthreads();
+    if (pv != k && t < b) {
+      const T a = g[k][t], c = g[pv][t];
+      g[k][t] = c;
+      g[pv][t] = a;
+    }
     __syncthreads();
     if (t < b && t >= k) g[t][k] = t == k ? from_real<T>(dk) : g[t][k] / from_real<T>(dk);
     __syncthreads();
     if (t < b && t > k)
-      for (int c = k + 1; c <= t; ++c) g[t][c] = Scal<T>::fnma(g[t][k], conj_of(g[c][k]), g[t][c]);  // lower triangle only
+      for (int c = k + 1; c < b; ++c) {  // trailing update of the whole square (Hermitian: g[t][c] -= l_t * conj(l_c))
+        g[t][c] = Scal<T>::fnma(g[t][k], conj_of(g[c][k]), g[t][c]);
+      }
+    if (t == 0) s_nacc = k + 1;
     __syncthreads();
   }
-  // inverse of the lower-triangular factor: thread c solves L x = e_c
-  if (t < b) {
-    for (int i = 0; i < b; ++i) li[i][t] = Scal<T>::zero();
+  __syncthreads();
+  const int na = s_nacc;
+  // inverse of the accepted lower-triangular factor: thread c solves L x = e_c
+  if (t < 32)
+    for (int i = 0; i < 32; ++i) li[i][t] = Scal<T>::zero();
+  __syncthreads();
+  if (t < na) {
     li[t][t] = Scal<T>::one() / g[t][t];
-    for (int i = t + 1; i < b; ++i) {
+    for (int i = t + 1; i < na; ++i) {
       T acc = Scal<T>::zero();
       for (int k = t; k < i; ++k) acc = Scal<T>::fma(g[i][k], li[k][t], acc);
       li[i][t] = (Scal<T>::zero() - acc) / g[i][i];
     }
   }
   __syncthreads();
-  if (t < 32)
+  if (t < 32) {
     for (int c = 0; c < 32; ++c) {
-      if (t < b && c < b) {
-        j.Lout[(size_t)t + (size_t)c * j.ldl] = c <= t ? g[t][c] : Scal<T>::zero();
-        j.Linv[(size_t)t + (size_t)c * 32] = li[t][c];
-      } else {
-        j.Linv[(size_t)t + (size_t)c * 32] = Scal<T>::zero();
-      }
+      const bool in = t < na && c < na;
+      if (in) j.Lout[(size_t)t + (size_t)c * j.ldl] = c <= t ? g[t][c] : Scal<T>::zero();
+      j.Linv[(size_t)t + (size_t)c * 32] = in ? li[t][c] : Scal<T>::zero();
     }
-  if (t < b) j.d[t] = real_of(g[t][t]);
-  if (t == 0 && j.first) *j.top = top;
+    // LinvP[:, perm[c]] = Linv[:, c]  (Q_new = Linv * W[perm, :] = LinvP * W)
+    for (int c = 0; c < 32; ++c) j.LinvP[(size_t)t + (size_t)c * 32] = Scal<T>::zero();
+  }
+  __syncthreads();
+  if (t < 32)
+    for (int c = 0; c < na; ++c) j.LinvP[(size_t)t + (size_t)perm[c] * 32] = t < na ? li[t][c] : Scal<T>::zero();
+  if (t < na) j.d[t] = real_of(g[t][t]);
+  __shared__ int oldp[32];
+  if (t < b) oldp[t] = j.p[t];
+  __syncthreads();
+  if (t < b) {
+    j.p[t] = oldp[perm[t]];
+    j.lperm[t] = perm[t];
+  }
+  if (t == 0) {
+    *j.nacc = na;
+    if (j.first) *j.top = top;
+  }
 }
 
 template <class T>
 struct QrJob {
   const T* M;     // m x q block whose rows are interpolated (ld ldm), left untouched
   int ldm, m, q;
-  const int* p;   // device: pivot order of the rows (m entries)
-  int rmax;       // rows worth orthogonalising: the rank the pivoted LU reported (an upper bound)
+  int* p;         // device: candidate order of the rows (m entries; the pivot order of a tournament-pivoted LU), re-ordered in place
+  int rmax;       // candidates: the first rmax rows of p
   // results
   int r = 0;
   double top = 0.0;      // d_0
@@ -500,19 +568,21 @@ struct QrJob {
   int ldt = 2;
 };
 
-// atol / rtol: rank = number of leading rows with d_j > max(atol, rtol * max(d_0, scale_floor))
+// rank = number of accepted rows: d_j > max(atol, rtol * max(d_0, scale_floor)) in a windowed-pivoted order (window: 32 candidates)
 template <class T>
 void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double atol, double rtol, double scale_floor, hipStream_t s) {
   const int nj = (int)jobs.size();
   if (nj == 0) return;
   struct St {
-    T *Q = nullptr, *Qh = nullptr, *L = nullptr, *Linv = nullptr, *W = nullptr, *Wh = nullptr, *C1 = nullptr, *C2 = nullptr, *G = nullptr;
+    T *Q = nullptr, *Qh = nullptr, *L = nullptr, *Linv = nullptr, *LinvP = nullptr, *W = nullptr, *Wh = nullptr, *C1 = nullptr, *C2 = nullptr, *G = nullptr;
     double *d = nullptr, *top = nullptr;
-    int ldq = 2, ldqh = 2, ldl = 2, done = 0, active = 1, nblk = 0;
-    std::vector<double> hd;
+    int *lperm = nullptr, *nacc = nullptr;
+    T* slab = nullptr;  // 32 x 32 slots for the blocks' inverse factors
+    int nslab = 0, used = 0;
+    int ldq = 2, ldqh = 2, ldl = 2, done = 0, active = 1, maxblk = 0, stall = 0;
+    std::vector<std::pair<int, int>> blocks;  // (offset, width) of the accepted blocks
   };
   std::vector<St> st(nj);
-  int maxsteps = 0;
   for (int a = 0; a < nj; ++a) {
     QrJob<T>& J = jobs[a];
     St& S = st[a];
@@ -522,15 +592,13 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       S.active = 0;
       continue;
     }
-    S.nblk = (J.rmax + 31) / 32;
-    maxsteps = std::max(maxsteps, S.nblk);
+    S.maxblk = J.rmax + 2;  // every step accepts at least one row or ends the job
     S.ldq = ev(J.rmax);
     S.ldqh = ev(J.q);
     S.ldl = ev(J.rmax);
     S.Q = tmp.get<T>((size_t)S.ldq * J.q);
     S.Qh = tmp.get<T>((size_t)S.ldqh * J.rmax);
     S.L = tmp.get<T>((size_t)S.ldl * J.rmax);
-    S.Linv = tmp.get<T>((size_t)S.nblk * 1024);
     S.W = tmp.get<T>((size_t)32 * J.q);
     S.Wh = tmp.get<T>((size_t)S.ldqh * 32);
     S.C1 = tmp.get<T>((size_t)32 * J.rmax);
@@ -538,96 +606,113 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     S.G = tmp.get<T>(1024);
     S.d = tmp.get<double>((size_t)J.rmax + 32);
     S.top = tmp.get<double>(4);
+    S.lperm = tmp.get<int>(32);
+    S.nslab = J.rmax / 16 + 8;
+    S.slab = tmp.get<T>((size_t)S.nslab * 2048);
     HSS_HIP(hipMemsetAsync(S.L, 0, sizeof(T) * (size_t)S.ldl * J.rmax, s));
-    S.hd.assign((size_t)J.rmax + 32, 0.0);
   }
+  int* dnacc = tmp.get<int>((size_t)nj);
+  for (int a = 0; a < nj; ++a) st[a].nacc = dnacc + a;
+  std::vector<int> hacc(nj, 0);
   std::vector<RowJob<T>> rows;
   std::vector<SubJob<T>> subs;
   std::vector<GemmProb<T>> g;
-  for (int step = 0; step < maxsteps; ++step) {
-    const int r0 = 32 * step;
+  std::vector<std::vector<T*>> linv(nj), linvp(nj);  // one 32 x 32 slot per accepted block
+  for (;;) {
     auto each = [&](auto&& f) {
       for (int a = 0; a < nj; ++a)
-        if (st[a].active && step < st[a].nblk) f(jobs[a], st[a], std::min(32, jobs[a].rmax - r0));
+        if (st[a].active) f(a, jobs[a], st[a], std::min(32, jobs[a].rmax - st[a].done));
     };
-    // W = M[p[r0 : r0+b], :]
-    each([&](QrJob<T>& J, St& S, int b) { rows.push_back(RowJob<T>{J.M, J.ldm, S.W, 32, J.p + r0, b, J.q, ROW_GATHER}); });
+    // W = M[p[done : done+b], :]
+    each([&](int, QrJob<T>& J, St& S, int b) { rows.push_back(RowJob<T>{J.M, J.ldm, S.W, 32, J.p + S.done, b, J.q, ROW_GATHER}); });
     if (rows.empty()) break;
     run_rows(tmp, rows, s);
-    if (r0 > 0) {
-      for (int pass = 0; pass < 2; ++pass) {  // classical Gram-Schmidt, twice
-        each([&](QrJob<T>& J, St& S, int b) {
-          T* Cx = pass == 0 ? S.C1 : S.C2;
-          HSS_HIP(hipMemsetAsync(Cx, 0, sizeof(T) * (size_t)32 * r0, s));
-          g.push_back(GemmProb<T>{S.W, S.Qh, Cx, b, r0, J.q, 32, S.ldqh, 32});
-        });
-        run_gemms(tmp, g, 0, s);
-        each([&](QrJob<T>& J, St& S, int b) { g.push_back(GemmProb<T>{pass == 0 ? S.C1 : S.C2, S.Q, S.W, b, J.q, r0, 32, S.ldq, 32}); });
-        run_gemms(tmp, g, 1, s);
-      }
-      // L[I, :r0] = C1 + C2
-      each([&](QrJob<T>& J, St& S, int b) {
-        rows.push_back(RowJob<T>{S.C1, 32, S.L + r0, S.ldl, nullptr, b, r0, ROW_GATHER});
-        (void)J;
+    for (int pass = 0; pass < 2; ++pass) {  // classical Gram-Schmidt against the accepted rows, twice
+      each([&](int, QrJob<T>& J, St& S, int b) {
+        if (S.done == 0) return;
+        T* Cx = pass == 0 ? S.C1 : S.C2;
+        HSS_HIP(hipMemsetAsync(Cx, 0, sizeof(T) * (size_t)32 * S.done, s));
+        g.push_back(GemmProb<T>{S.W, S.Qh, Cx, b, S.done, J.q, 32, S.ldqh, 32});
       });
-      run_rows(tmp, rows, s);
-      each([&](QrJob<T>& J, St& S, int b) {
-        rows.push_back(RowJob<T>{S.C2, 32, S.L + r0, S.ldl, nullptr, b, r0, ROW_SCATTER_ADD});
-        (void)J;
+      run_gemms(tmp, g, 0, s);
+      each([&](int, QrJob<T>& J, St& S, int b) {
+        if (S.done > 0) g.push_back(GemmProb<T>{pass == 0 ? S.C1 : S.C2, S.Q, S.W, b, J.q, S.done, 32, S.ldq, 32});
       });
-      run_rows(tmp, rows, s);
+      run_gemms(tmp, g, 1, s);
     }
-    // G = W * W^H, Cholesky-QR of the block
-    each([&](QrJob<T>& J, St& S, int b) { subs.push_back(SubJob<T>{S.W, 32, nullptr, nullptr, 0, 0, b, J.q, S.Wh, S.ldqh, 2}); });
+    each([&](int, QrJob<T>&, St& S, int b) {  // C1 += C2: the coefficients of the candidates against the accepted rows
+      if (S.done > 0) rows.push_back(RowJob<T>{S.C2, 32, S.C1, 32, nullptr, b, S.done, ROW_SCATTER_ADD});
+    });
+    run_rows(tmp, rows, s);
+    // G = W * W^H, pivoted Cholesky of the window
+    each([&](int, QrJob<T>& J, St& S, int b) { subs.push_back(SubJob<T>{S.W, 32, nullptr, nullptr, 0, 0, b, J.q, S.Wh, S.ldqh, 2}); });
     run_subs(tmp, subs, s);
     std::vector<CholJob<T>> cj;
-    each([&](QrJob<T>& J, St& S, int b) {
+    each([&](int a, QrJob<T>& J, St& S, int b) {
       HSS_HIP(hipMemsetAsync(S.G, 0, sizeof(T) * 1024, s));
       g.push_back(GemmProb<T>{S.W, S.Wh, S.G, b, b, J.q, 32, S.ldqh, 32});
-      cj.push_back(CholJob<T>{S.G, S.L + r0 + (size_t)r0 * S.ldl, S.ldl, S.Linv + (size_t)step * 1024, S.d + r0, S.top, b, step == 0 ? 1 : 0});
+      T* slot = S.used < S.nslab ? S.slab + (size_t)(S.used++) * 2048 : tmp.get<T>(2048);
+      linv[a].push_back(slot);
+      linvp[a].push_back(slot + 1024);
+      cj.push_back(CholJob<T>{S.G, S.L + S.done + (size_t)S.done * S.ldl, S.ldl, slot, slot + 1024, S.d + S.done, S.top, J.p + S.done, S.lperm, S.nacc, atol, rtol,
+                              scale_floor, b, S.done == 0 ? 1 : 0});
     });
     run_gemms(tmp, g, 0, s);
     CholJob<T>* dcj = upload(tmp, cj);
     hipLaunchKernelGGL(chol_block_kernel<T>, dim3((unsigned)cj.size()), dim3(64), 0, s, (const CholJob<T>*)dcj);
-    // Q[I, :] = Linv * W, Qh[:, I] = Q[I, :]^H
-    each([&](QrJob<T>& J, St& S, int b) {
-      HSS_HIP(hipMemset2DAsync(S.Q + r0, sizeof(T) * S.ldq, 0, sizeof(T) * b, J.q, s));
-      g.push_back(GemmProb<T>{S.Linv + (size_t)step * 1024, S.W, S.Q + r0, b, J.q, b, 32, 32, S.ldq});
+    // how many candidates each job accepted
+    HSS_HIP(hipMemcpyAsync(hacc.data(), dnacc, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, s));
+    HSS_HIP(hipStreamSynchronize(s));
+    // Q[done : done+b', :] = LinvP * W, its conjugate transpose, and the rows of L against the earlier blocks (in accepted order)
+    each([&](int a, QrJob<T>& J, St& S, int b) {
+      const int na = hacc[a];
+      if (na <= 0) return;
+      HSS_HIP(hipMemset2DAsync(S.Q + S.done, sizeof(T) * S.ldq, 0, sizeof(T) * na, J.q, s));
+      g.push_back(GemmProb<T>{linvp[a].back(), S.W, S.Q + S.done, na, J.q, b, 32, 32, S.ldq});
+      if (S.done > 0) rows.push_back(RowJob<T>{S.C1, 32, S.L + S.done, S.ldl, S.lperm, na, S.done, ROW_GATHER});
     });
     run_gemms(tmp, g, 0, s);
-    each([&](QrJob<T>& J, St& S, int b) { subs.push_back(SubJob<T>{S.Q + r0, S.ldq, nullptr, nullptr, 0, 0, b, J.q, S.Qh + (size_t)r0 * S.ldqh, S.ldqh, 2}); });
+    run_rows(tmp, rows, s);
+    each([&](int a, QrJob<T>& J, St& S, int) {
+      const int na = hacc[a];
+      if (na > 0) subs.push_back(SubJob<T>{S.Q + S.done, S.ldq, nullptr, nullptr, 0, 0, na, J.q, S.Qh + (size_t)S.done * S.ldqh, S.ldqh, 2});
+    });
     run_subs(tmp, subs, s);
-    // the block's diagonal: decide which jobs go on
-    each([&](QrJob<T>& J, St& S, int b) {
-      HSS_HIP(hipMemcpyAsync(S.hd.data() + r0, S.d + r0, sizeof(double) * b, hipMemcpyDeviceToHost, s));
-      (void)J;
-    });
-    HSS_HIP(hipStreamSynchronize(s));
-    each([&](QrJob<T>& J, St& S, int b) {
-      if (step == 0) J.top = S.hd[0];
-      const double tau = std::max(atol, rtol * std::max(J.top, scale_floor));
-      S.done = r0 + b;
-      bool any = false;
-      for (int i = 0; i < b; ++i) any = any || S.hd[(size_t)r0 + i] > tau;
-      if (!any) S.active = 0;  // a whole block below the threshold: the rank has been passed
-    });
+    HSS_HIP(hipStreamSynchronize(s));  // lperm / nacc are rewritten by the next window
+    for (int a = 0; a < nj; ++a) {
+      St& S = st[a];
+      if (!S.active) continue;
+      const int b = std::min(32, jobs[a].rmax - S.done), na = hacc[a];
+      if (na > 0) {
+        S.blocks.push_back({S.done, na});
+        S.done += na;
+      } else {
+        linv[a].pop_back();
+        linvp[a].pop_back();
+      }
+      // fewer accepted than offered: the first rejected candidate was below the truncation threshold (the job is finished) or badly
+      // conditioned against the rows accepted in this window (it is looked at again, orthogonalised against them); a window that
+      // accepts nothing ends the job
+      if (S.done >= jobs[a].rmax || na == 0) S.active = 0;
+      (void)b;
+    }
+    // a rejected candidate above the threshold keeps the job going; one below it ends the job -- told apart by the next window: its first pivot is then <= tau
   }
-  // ranks
-  int maxR = 0, maxr = 0;
+  // ranks and d_0
+  int maxblocks = 0;
   for (int a = 0; a < nj; ++a) {
     QrJob<T>& J = jobs[a];
     St& S = st[a];
-    const double tau = std::max(atol, rtol * std::max(J.top, scale_floor));
-    int r = 0;
-    for (int i = 0; i < S.done; ++i)
-      if (S.hd[(size_t)i] > tau) r = i + 1;
-    J.r = r;
-    J.ldt = ev(J.m - r);
-    J.Tm = out_pool.get<T>((size_t)J.ldt * std::max(r, 1));
-    maxR = std::max(maxR, J.m - r);
-    maxr = std::max(maxr, r);
+    J.r = S.done;
+    J.ldt = ev(J.m - J.r);
+    J.Tm = out_pool.get<T>((size_t)J.ldt * std::max(J.r, 1));
+    maxblocks = std::max(maxblocks, (int)S.blocks.size());
+    if (S.top) HSS_HIP(hipMemcpyAsync(&J.top, S.top, sizeof(double), hipMemcpyDeviceToHost, s));
   }
-  // T = (M[p_R, :] * Q_S^H) * L_SS^-1, column blocks of 32 from the right
+  HSS_HIP(hipStreamSynchronize(s));
+  for (int a = 0; a < nj; ++a)
+    if (jobs[a].r == 0) jobs[a].top = std::max(jobs[a].top, 0.0);
+  // T = (M[p_R, :] * Q_S^H) * L_SS^-1, block columns from the right
   std::vector<T*> YR(nj, nullptr), T2(nj, nullptr);
   for (int a = 0; a < nj; ++a) {
     QrJob<T>& J = jobs[a];
@@ -642,19 +727,18 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
   }
   run_rows(tmp, rows, s);
   run_gemms(tmp, g, 0, s);  // Tm <- L_RS
-  for (int j0 = (maxr - 1) / 32 * 32; j0 >= 0; j0 -= 32) {
+  for (int step = 0; step < maxblocks; ++step) {
     std::vector<GemmProb<T>> g1, g2;
     std::vector<SubJob<T>> back;
     for (int a = 0; a < nj; ++a) {
       QrJob<T>& J = jobs[a];
       St& S = st[a];
-      const int nR = J.m - J.r, r = J.r;
-      if (nR <= 0 || r <= j0) continue;
-      const int j1 = std::min(j0 + 32, r), w = j1 - j0;
+      const int nR = J.m - J.r, r = J.r, nb_ = (int)S.blocks.size();
+      if (nR <= 0 || step >= nb_) continue;
+      const int bi = nb_ - 1 - step, j0 = S.blocks[bi].first, w = S.blocks[bi].second, j1 = j0 + w;
       if (r > j1) g1.push_back(GemmProb<T>{J.Tm + (size_t)j1 * J.ldt, S.L + j1 + (size_t)j0 * S.ldl, J.Tm + (size_t)j0 * J.ldt, nR, w, r - j1, J.ldt, S.ldl, J.ldt});
-      // the leading w x w part of the block's inverse is the inverse of the leading part of its factor (lower triangular)
       HSS_HIP(hipMemsetAsync(T2[a], 0, sizeof(T) * (size_t)ev(nR) * 32, s));
-      g2.push_back(GemmProb<T>{J.Tm + (size_t)j0 * J.ldt, S.Linv + (size_t)(j0 / 32) * 1024, T2[a], nR, w, w, J.ldt, 32, ev(nR)});
+      g2.push_back(GemmProb<T>{J.Tm + (size_t)j0 * J.ldt, linv[a][bi], T2[a], nR, w, w, J.ldt, 32, ev(nR)});
       back.push_back(SubJob<T>{T2[a], ev(nR), nullptr, nullptr, 0, 0, nR, w, J.Tm + (size_t)j0 * J.ldt, J.ldt, 0});
     }
     run_gemms(tmp, g1, 1, s);
