@@ -119,7 +119,11 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
       jobs[2 * i] = LowRankJob<T>{hd[i].UR, hd[i].ldu, hd[i].ni, hd[i].nb, kR, seed, RR[i], 0};
       jobs[2 * i + 1] = LowRankJob<T>{hd[i].LF + hd[i].ni, hd[i].ldl, hd[i].nb, hd[i].ni, kL, seed + 1, LL[i], 0};
     }
-    int st = lowrank_compress_batch<T>(jobs.data(), 2 * count, 0.5 * h->opts.atol, 0.5 * h->opts.rtol, s);
+    // `pqrfact` at 0.5*atol, 0.5*rtol (factorization.jl:99-100): interpolative form, rank and interpolation from the orthogonalisation of the
+    // sketch rows in tournament-pivot order (lowrank_id_batch); HS_LR_QR=0 keeps the LU-based rank rule and factors (diagnostics)
+    static const bool lr_qr = !(getenv("HS_LR_QR") && getenv("HS_LR_QR")[0] == '0');
+    int st = lr_qr ? lowrank_id_batch<T>(jobs.data(), 2 * count, 0.5 * h->opts.atol, 0.5 * h->opts.rtol, s)
+                   : lowrank_compress_batch<T>(jobs.data(), 2 * count, 0.5 * h->opts.atol, 0.5 * h->opts.rtol, s);
     if (st != 0) throw HsError{st};
   }
   for (int i = 0; i < count; ++i) {

@@ -561,6 +561,7 @@ struct QrJob {
   int ldm, m, q;
   int* p;         // device: candidate order of the rows (m entries; the pivot order of a tournament-pivoted LU), re-ordered in place
   int rmax;       // candidates: the first rmax rows of p
+  double atol_scale = 1.0;  // the absolute tolerance is multiplied by this (rows of an un-normalised Gaussian sketch are sqrt(k) times longer)
   // results
   int r = 0;
   double top = 0.0;      // d_0
@@ -654,8 +655,8 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       T* slot = S.used < S.nslab ? S.slab + (size_t)(S.used++) * 2048 : tmp.get<T>(2048);
       linv[a].push_back(slot);
       linvp[a].push_back(slot + 1024);
-      cj.push_back(CholJob<T>{S.G, S.L + S.done + (size_t)S.done * S.ldl, S.ldl, slot, slot + 1024, S.d + S.done, S.top, J.p + S.done, S.lperm, S.nacc, atol, rtol,
-                              scale_floor, b, S.done == 0 ? 1 : 0});
+      cj.push_back(CholJob<T>{S.G, S.L + S.done + (size_t)S.done * S.ldl, S.ldl, slot, slot + 1024, S.d + S.done, S.top, J.p + S.done, S.lperm, S.nacc, atol * J.atol_scale,
+                              rtol, scale_floor, b, S.done == 0 ? 1 : 0});
     });
     run_gemms(tmp, g, 0, s);
     CholJob<T>* dcj = upload(tmp, cj);
@@ -1765,7 +1766,76 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
   return H.release();
 }
 
+// C (rows x r, original row order) = P' [I; T]: row p[i] = e_i for i < r, row p[r + i] = T[i, :]
+template <class T>
+__global__ __launch_bounds__(256) void id_expand_kernel(const int* __restrict__ p, const T* __restrict__ Tm, int ldt, int rows, int r, T* __restrict__ C, int ldc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  const int orow = p[i];
+  for (int j = 0; j < r; ++j) C[(size_t)orow + (size_t)j * ldc] = i < r ? (i == j ? Scal<T>::one() : Scal<T>::zero()) : Tm[(size_t)(i - r) + (size_t)j * ldt];
+}
+
 }  // namespace
+
+template <class T>
+int lowrank_id_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s) {
+  // pivot order: tournament-pivoted LU of the sketches (its own rank estimate only sizes the sketch)
+  int st = lowrank_compress_batch<T>(jobs, njobs, atol, rtol, s, false, true);
+  if (st != 0) return st;
+  try {
+    Pool tmp, keep;
+    std::vector<QrJob<T>> qj;
+    std::vector<int> idx;
+    for (int a = 0; a < njobs; ++a) {
+      LowRank<T>& o = *jobs[a].out;
+      if (o.rows <= 0 || o.cols <= 0 || !o.Y0) continue;
+      QrJob<T> q;
+      q.M = o.Y0;
+      q.ldm = o.ldp;
+      q.m = o.rows;
+      q.q = o.k;
+      q.p = o.rperm;
+      q.rmax = o.k;
+      q.atol_scale = std::sqrt((double)o.k);  // the sketch is not normalised: |row of X*Omega| ~ sqrt(k) |row of X|
+      qj.push_back(q);
+      idx.push_back(a);
+    }
+    qr_refine<T>(tmp, keep, qj, atol, rtol, 0.0, s);
+    std::vector<RowJob<T>> rows;
+    for (size_t b = 0; b < qj.size(); ++b) {
+      LowRankJob<T>& J = jobs[idx[b]];
+      LowRank<T>& o = *J.out;
+      const int r = qj[b].r;
+      o.r = r;
+      o.top = qj[b].top;
+      o.ldz = std::max(2, (r + 1) / 2 * 2);
+      o.ldc = std::max(2, (o.rows + 1) / 2 * 2);
+      if (hipMalloc((void**)&o.Z, sizeof(T) * ((size_t)o.ldz * J.cols + 32)) != hipSuccess ||
+          hipMalloc((void**)&o.Cd, sizeof(T) * ((size_t)o.ldc * std::max(r, 1) + 32)) != hipSuccess) {
+        hs_set_error(HS_ERR_NOMEM, 0, "hipMalloc of a low-rank factor (%d x %d) failed", r, J.cols);
+        return HS_ERR_NOMEM;
+      }
+      if (r > 0) {
+        rows.push_back(RowJob<T>{J.X, J.ldx, o.Z, o.ldz, o.rperm, r, J.cols, ROW_GATHER});  // Z = the skeleton rows of X
+        hipLaunchKernelGGL(id_expand_kernel<T>, dim3((o.rows + 255) / 256), dim3(256), 0, s, (const int*)o.rperm, (const T*)qj[b].Tm, qj[b].ldt, o.rows, r, o.Cd, o.ldc);
+      }
+    }
+    run_rows(tmp, rows, s);
+    HSS_HIP(hipStreamSynchronize(s));
+    for (int a = 0; a < njobs; ++a) {  // the packed LU and the sketch copy are not needed again
+      LowRank<T>& o = *jobs[a].out;
+      if (o.Lp) (void)hipFree(o.Lp);
+      if (o.Y0) (void)hipFree(o.Y0);
+      o.Lp = nullptr;
+      o.Y0 = nullptr;
+    }
+  } catch (int code) {
+    return code;
+  }
+  return 0;
+}
+template int lowrank_id_batch<double>(LowRankJob<double>*, int, double, double, hipStream_t);
+template int lowrank_id_batch<cplx>(LowRankJob<cplx>*, int, double, double, hipStream_t);
 
 struct hs_hss {
   int is_complex;

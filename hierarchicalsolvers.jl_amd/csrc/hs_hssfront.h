@@ -223,7 +223,9 @@ static void factor_hss_fronts(hs_handle* h, const int* ids, int count, const Nod
       jobs[2 * a] = LowRankJob<T>{hd[i].UR, hd[i].ldu, hd[i].ni, hd[i].nb, kR, seed, RR[a], 0};
       jobs[2 * a + 1] = LowRankJob<T>{hd[i].LF + hd[i].ni, hd[i].ldl, hd[i].nb, hd[i].ni, kL, seed + 1, LL[a], 0};
     }
-    const int st = lowrank_compress_batch<T>(jobs.data(), 2 * nw, 0.5 * h->opts.atol, 0.5 * h->opts.rtol, s);  // factorization.jl:99-100
+    static const bool lr_qr = !(getenv("HS_LR_QR") && getenv("HS_LR_QR")[0] == '0');
+    const int st = lr_qr ? lowrank_id_batch<T>(jobs.data(), 2 * nw, 0.5 * h->opts.atol, 0.5 * h->opts.rtol, s)
+                         : lowrank_compress_batch<T>(jobs.data(), 2 * nw, 0.5 * h->opts.atol, 0.5 * h->opts.rtol, s);  // factorization.jl:99-100
     if (st != 0) throw HsError{st};
   }
   std::vector<T*> W2(nw, nullptr), W3(nw, nullptr);

@@ -12,6 +12,7 @@ struct LowRank {
   double top = 0.0;     // |u_11| of the pivoted sketch: the scale the relative tolerance was applied to
   T* Cd = nullptr;      // optional dense C (rows x r, ld = ldc) in ORIGINAL row order; when set it replaces P'*trap(Lp)
   int ldc = 0;
+  T* Y0 = nullptr;      // optional copy of the sketch X*Omega (rows x k, ld = ldp) taken before its pivoted LU (keep_sketch)
 };
 
 template <class T>
@@ -31,7 +32,13 @@ struct LowRankJob {
 template <class T>
 // need_z = false: only the pivoted LU of the sketch, the row permutation and the rank are wanted (the HSS module takes its
 // interpolation matrices from them): Z is not formed and X is left as it was
-int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z = true);
+int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z = true, bool keep_sketch = false);
+// hs_hss.hip: the interpolative form X ~= C*Z with Z = r ROWS of X and C = P'[I; T] -- pivot order from the tournament-pivoted LU of the
+// sketch, rank (tolerance-stopped) and least-squares T from the windowed-pivoted orthogonalisation of the sketch rows (qr_refine): the role
+// of `pqrfact(X; atol, rtol)` (rank-revealing QR) in `_lgauss_transform` / `_rgauss_transform` (src/factorization.jl:171-182).  X is left
+// untouched; out->Cd (dense, original row order), out->Z, out->r, out->rperm are set, the packed LU is released.
+template <class T>
+int lowrank_id_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s);
 // hs_lrdense.hip
 template <class T>
 void lowrank_expand(LowRank<T>& lr, hipStream_t s);  // fills Cd from the trapezoid form

@@ -65,6 +65,7 @@ void lowrank_free(LowRank<T>& lr) {
   if (lr.Z) (void)hipFree(lr.Z);
   if (lr.rperm) (void)hipFree(lr.rperm);
   if (lr.Cd) (void)hipFree(lr.Cd);
+  if (lr.Y0) (void)hipFree(lr.Y0);
   lr = LowRank<T>();
 }
 

@@ -79,7 +79,7 @@ struct Guard {  // frees what it was given, whatever the exit path
   } while (0)
 
 template <class T>
-int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z) {
+int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z, bool keep_sketch) {
   std::vector<int> todo;
   for (int i = 0; i < njobs; ++i) {
     LowRankJob<T>& J = jobs[i];
@@ -172,8 +172,11 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
       d.mcols[2] = 0;
       hdj[a] = DiagJob<T>{Y[a], ldp[a], J.k, dDg + offDg[a]};
     }
+    std::vector<T*> Y0(nj, nullptr);
     auto free_Y = [&]() {
       for (T* y : Y)
+        if (y) (void)hipFree(y);
+      for (T* y : Y0)
         if (y) (void)hipFree(y);
     };
     hipError_t e = hipMemcpyAsync(dn, hn.data(), sizeof(NodeDesc<T>) * nj, hipMemcpyHostToDevice, s);
@@ -186,6 +189,18 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
       return -6;
     }
     launch_gemm_probs<T>(dgp, nj, maxrows, maxk, 0, s);  // Y = X * Omega, all blocks
+    if (keep_sketch) {  // the orthogonalisation that refines rank and interpolation reads the sketch itself, not its L\U
+      for (int a = 0; a < nj; ++a) {
+        const LowRankJob<T>& J = jobs[todo[a]];
+        const size_t el = (size_t)ldp[a] * J.k + 32;
+        if (hipMalloc((void**)&Y0[a], sizeof(T) * el) != hipSuccess) {
+          free_Y();
+          hs_set_error(-7, 0, "hipMalloc of a %d x %d sketch copy failed", J.rows, J.k);
+          return -7;
+        }
+        (void)hipMemcpyAsync(Y0[a], Y[a], sizeof(T) * (size_t)ldp[a] * J.k, hipMemcpyDeviceToDevice, s);
+      }
+    }
     launch_init_fronts<T>(dn, nj, maxrows, s);
     Sched<T> sch{dn, nj, maxk, maxcols, maxrows, s, &prof, nullptr, nullptr, nullptr, maxrows};
     int P2 = HS_PB;
@@ -217,6 +232,8 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
         next.push_back(todo[a]);
         (void)hipFree(Y[a]);
         Y[a] = nullptr;
+        if (Y0[a]) (void)hipFree(Y0[a]);
+        Y0[a] = nullptr;
         hn[a].mcols[1] = 0;  // takes no part in the second phase of this pass
         hn[a].mrows[1] = 0;
         rank[a] = -1;
@@ -254,6 +271,8 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
         (void)hipMemcpyAsync(o.rperm, hn[a].rperm, sizeof(int) * J.rows, hipMemcpyDeviceToDevice, s);
         o.Lp = Y[a];
         Y[a] = nullptr;
+        o.Y0 = Y0[a];
+        Y0[a] = nullptr;
         o.ldp = ldp[a];
         o.k = J.k;
         o.r = r;
@@ -266,5 +285,5 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
   return 0;
 }
 
-template int lowrank_compress_batch<double>(LowRankJob<double>*, int, double, double, hipStream_t, bool);
-template int lowrank_compress_batch<cplx>(LowRankJob<cplx>*, int, double, double, hipStream_t, bool);
+template int lowrank_compress_batch<double>(LowRankJob<double>*, int, double, double, hipStream_t, bool, bool);
+template int lowrank_compress_batch<cplx>(LowRankJob<cplx>*, int, double, double, hipStream_t, bool, bool);
