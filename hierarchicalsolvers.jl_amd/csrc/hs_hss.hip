@@ -23,6 +23,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/hs_hss.h"
@@ -181,14 +182,21 @@ __global__ __launch_bounds__(64) void idx_compose_kernel(const IdxJob* __restric
 // ------------------------------------------------------------------------------------------------
 // host structures
 // ------------------------------------------------------------------------------------------------
-// Device blocks that the sweeps allocate over and over (hundreds of small blocks per hs_hss_ldiv) are recycled through a
-// per-matrix cache: size classes of powers of two, blocks above 64 MiB go straight back to the driver.
+// Device blocks that the module allocates over and over (hundreds of small blocks per sweep, thousands per compression: every
+// hipMalloc / hipFree costs 0.1-0.3 ms and a hipFree synchronises the device) are recycled through ONE process-wide cache: size
+// classes of powers of two, blocks above 64 MiB go straight back to the driver.  The cache is never destroyed (its blocks return to
+// the driver with the process; a static destructor would run after the HIP runtime has shut down) and is guarded by a mutex:
+// distinct handles may be used from different threads.
 struct BlockCache {
   std::multimap<size_t, void*> free_;
-  ~BlockCache() {
-    for (auto& kv : free_) (void)hipFree(kv.second);
-  }
+  std::mutex mu;
+  size_t held = 0;
+  static constexpr size_t limit = (size_t)24 << 30;  // bytes the cache may hold back; beyond it freed blocks go to the driver
 };
+static BlockCache* global_cache() {
+  static BlockCache* g = new BlockCache();
+  return g;
+}
 struct Pool {
   std::vector<std::pair<void*, size_t>> v;
   BlockCache* cache = nullptr;
@@ -198,33 +206,53 @@ struct Pool {
   Pool& operator=(const Pool&) = delete;
   ~Pool() { clear(); }
   void clear() {
-    for (auto& pr : v) {
-      if (cache && pr.second <= ((size_t)64 << 20))
-        cache->free_.insert({pr.second, pr.first});
-      else
-        (void)hipFree(pr.first);
+    if (cache) {
+      std::lock_guard<std::mutex> lk(cache->mu);
+      for (auto& pr : v) {
+        if (pr.second <= ((size_t)64 << 20) + 4096 && cache->held + pr.second <= BlockCache::limit) {
+          cache->free_.insert({pr.second, pr.first});
+          cache->held += pr.second;
+        } else {
+          (void)hipFree(pr.first);
+        }
+      }
+    } else {
+      for (auto& pr : v) (void)hipFree(pr.first);
     }
     v.clear();
   }
   template <class U>
   U* get(size_t count) {
     size_t bytes = count * sizeof(U) + 512;
-    if (cache) {
+    if (cache && bytes <= ((size_t)64 << 20)) {  // larger blocks are allocated exactly and go straight back to the driver
       size_t cls = 1024;
       while (cls < bytes) cls <<= 1;
+      if (cls > 4096 && cls - cls / 4 >= bytes) cls -= cls / 4;  // a 3/4 class in between: at most 1/3 of a block is slack
       bytes = cls;
+      std::lock_guard<std::mutex> lk(cache->mu);
       auto it = cache->free_.find(bytes);
       if (it != cache->free_.end()) {
         void* p = it->second;
         cache->free_.erase(it);
+        cache->held -= bytes;
         v.push_back({p, bytes});
         return (U*)p;
       }
     }
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {
-      hs_set_error(HS_ERR_NOMEM, 0, "hipMalloc of %zu bytes failed (HSS module)", bytes);
-      throw (int)HS_ERR_NOMEM;
+      (void)hipGetLastError();
+      if (cache) {  // give the cached blocks back to the driver and try once more
+        std::lock_guard<std::mutex> lk(cache->mu);
+        for (auto& kv : cache->free_) (void)hipFree(kv.second);
+        cache->free_.clear();
+        cache->held = 0;
+      }
+      if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        hs_set_error(HS_ERR_NOMEM, 0, "hipMalloc of %zu bytes failed (HSS module)", bytes);
+        throw (int)HS_ERR_NOMEM;
+      }
     }
     v.push_back({p, bytes});
     return (U*)p;
@@ -271,14 +299,13 @@ struct HssT {
   hs_hss_options opt;
   std::vector<HNode<T>> nd;
   std::vector<std::vector<int>> lev;
-  BlockCache cache;  // recycled temporaries of the sweeps (declared first: destroyed last)
-  Pool keep;         // generators and factors
+  Pool keep{global_cache()};  // generators and factors (blocks recycle through the process-wide cache)
   hipStream_t s = nullptr;
   bool own_stream = false;
   int* perm = nullptr;  // device, n entries (0-based) or null: H ~= A[perm, perm]
   std::vector<int> hinvperm;  // host: position of every caller index in the tree's order (empty: identity)
   std::vector<int> hperm;     // host copy of perm (empty: identity)
-  Pool permpool;
+  Pool permpool{global_cache()};
   bool factored = false;
   NodeDesc<T> rootfd;  // LU of the last block
   int root_m = 0;
@@ -755,7 +782,7 @@ template <class T>
 bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = Lru<T>(), BlockOp<T>* bop = nullptr) {
   const int n = H.n;
   hipStream_t s = H.s;
-  Pool tmp(&H.cache);  // samples and everything else that dies with this attempt
+  Pool tmp(global_cache());  // samples and everything else that dies with this attempt
   H.keep.clear();
   build_tree(H, n, (int)H.opt.leafsize, (int)H.opt.first_split);
   H.k = k;
@@ -1168,7 +1195,7 @@ void hss_mul(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q, bool trans =
     hss_mul_p(H, X, ldx, Y, ldy, q, trans);
     return;
   }
-  Pool tmp(&H.cache);
+  Pool tmp(global_cache());
   const int ld = ev(H.n);
   T* Xp = tmp.get<T>((size_t)ld * q);
   T* Yp = tmp.get<T>((size_t)ld * q);
@@ -1184,7 +1211,7 @@ void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q, bool trans
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
-  Pool tmp(&H.cache);
+  Pool tmp(global_cache());
   std::vector<RowJob<T>> rows;
   std::vector<GemmProb<T>> gemms;
   if (trans) {  // H^T has the same bases (U = V) and the generators D^T, B12 <- B21^T, B21 <- B12^T: transposed copies on first use
@@ -1326,7 +1353,7 @@ void hss_basis(HssT<T>& H, int node, T* out, int ldo) {
     hs_set_error(HS_ERR_ARGUMENT, node, "ArgumentError: HSS node %d has no basis (the root has none)", node);
     throw (int)HS_ERR_ARGUMENT;
   }
-  Pool tmp(&H.cache);
+  Pool tmp(global_cache());
   // the subtree, by level
   std::vector<std::vector<int>> lv(H.nlev);
   std::vector<int> cur{node};
@@ -1454,7 +1481,7 @@ void hss_factor(HssT<T>& H) {
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
-  Pool tmp(&H.cache);
+  Pool tmp(global_cache());
   std::vector<SubJob<T>> subs;
   std::vector<GemmProb<T>> gemms;
   auto t0 = std::chrono::steady_clock::now();
@@ -1576,7 +1603,7 @@ void hss_ldiv(HssT<T>& H, T* B, int ldb, int q) {
     hss_ldiv_p(H, B, ldb, q);
     return;
   }
-  Pool tmp(&H.cache);
+  Pool tmp(global_cache());
   const int ld = ev(H.n);
   T* Bp = tmp.get<T>((size_t)ld * q);
   std::vector<RowJob<T>> rows{RowJob<T>{B, ldb, Bp, ld, H.perm, H.n, q, ROW_GATHER}};
@@ -1591,7 +1618,7 @@ void hss_ldiv_p(HssT<T>& H, T* B, int ldb, int q) {
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
-  Pool tmp(&H.cache);
+  Pool tmp(global_cache());
   std::vector<RowJob<T>> rows;
   std::vector<GemmProb<T>> gemms;
   std::vector<NodeDesc<T>> descs;
@@ -1715,7 +1742,7 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
     H->perm = H->permpool.template get<int>((size_t)n);
     HSS_HIP(hipMemcpy(H->perm, hp.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
   }
-  Pool in;
+  Pool in(global_cache());
   const T* dA = A;
   int ld = (int)lda;
   if (where == 0 && !bop) {
@@ -1783,7 +1810,7 @@ int lowrank_id_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, h
   int st = lowrank_compress_batch<T>(jobs, njobs, atol, rtol, s, false, true);
   if (st != 0) return st;
   try {
-    Pool tmp, keep;
+    Pool tmp(global_cache()), keep(global_cache());
     std::vector<QrJob<T>> qj;
     std::vector<int> idx;
     for (int a = 0; a < njobs; ++a) {
@@ -1995,7 +2022,7 @@ static void with_device_block(int n, const T* Bin, int64_t ldin, T* Bout, int64_
     f(Bin, (int)ldin, Bout, (int)ldout);
     return;
   }
-  Pool st;
+  Pool st(global_cache());
   const int ld = ev(n);
   T* dI = st.get<T>((size_t)ld * q);
   T* dO = (Bout == Bin) ? dI : st.get<T>((size_t)ld * q);
@@ -2097,7 +2124,7 @@ extern "C" int hs_hss_getindex(hs_hss* H, const int64_t* I, int64_t ni, const in
         if (H->is_complex) hss_getindex<cplx>(*HZ(H), I, (int)ni, J, (int)nj, (cplx*)out, (int)ldo);
         else hss_getindex<double>(*HD(H), I, (int)ni, J, (int)nj, out, (int)ldo);
       } else {
-        Pool st;
+        Pool st(global_cache());
         const int ld = ev((int)ni);
         if (H->is_complex) {
           cplx* d = st.get<cplx>((size_t)ld * nj);
@@ -2130,7 +2157,7 @@ extern "C" int hs_hss_basis(hs_hss* H, int64_t node, double* out, int64_t ldo, i
         if (H->is_complex) hss_basis<cplx>(*HZ(H), (int)node, (cplx*)out, (int)ldo);
         else hss_basis<double>(*HD(H), (int)node, out, (int)ldo);
       } else {
-        Pool st;
+        Pool st(global_cache());
         const int ld = ev(rows);
         if (H->is_complex) {
           cplx* d = st.get<cplx>((size_t)ld * r);
@@ -2155,7 +2182,7 @@ static void offdiag_impl(HssT<T>& H, int which, T* C_, int ldc, T* Z, int ldz) {
     throw (int)HS_ERR_HSS_LEAF;
   }
   hipStream_t s = H.s;
-  Pool tmp(&H.cache);
+  Pool tmp(global_cache());
   const int a = which == 0 ? H.nd[0].left : H.nd[0].right, b = which == 0 ? H.nd[0].right : H.nd[0].left;
   const int na = H.nd[a].hi - H.nd[a].lo, nb = H.nd[b].hi - H.nd[b].lo, ra = H.nd[a].r, rb = H.nd[b].r;
   if (ldc < na || ldz < rb) {
@@ -2193,7 +2220,7 @@ extern "C" int hs_hss_offdiag(hs_hss* H, int which, double* C_, int64_t ldc, dou
         if (H->is_complex) offdiag_impl<cplx>(*HZ(H), which, (cplx*)C_, (int)ldc, (cplx*)Z, (int)ldz);
         else offdiag_impl<double>(*HD(H), which, C_, (int)ldc, Z, (int)ldz);
       } else {
-        Pool st;
+        Pool st(global_cache());
         const int lc = ev(na), lz = ev(rb);
         const size_t esz = H->is_complex ? 16 : 8;
         void* dC = st.get<char>((size_t)lc * std::max(rb, 1) * esz);

@@ -170,7 +170,7 @@ void hss_getindex_batch(HssT<T>& H, const std::vector<GiJob<T>>& jobs) {
   const int N = (int)nd.size();
   const int B = (int)jobs.size();
   if (B == 0) return;
-  Pool tmp(&H.cache);
+  Pool tmp(global_cache());
   struct JS {
     std::vector<int> oI, oJ, sI, sJ;  // order and sorted tree positions
     T* outS = nullptr;
@@ -385,7 +385,7 @@ struct BlockOp {
   int* gid = nullptr;           // device copy
   int* lpos = nullptr;          // device, A.n entries, -1 outside the operator (set by begin(), restored by end())
   SparseDev<T> A;
-  Pool own;
+  Pool own{global_cache()};
 
   void begin(hipStream_t s) {
     gid = own.get<int>((size_t)std::max(n, 1));

@@ -191,23 +191,36 @@ static int lowrank_hook(int64_t rows, int64_t cols, const T* X, double atol, dou
   const int ldx = ((int)rows + 1) / 2 * 2;
   CK(hipMalloc((void**)&dX, sizeof(T) * ((size_t)ldx * cols + 32)));
   CK(hipMemcpy2D(dX, sizeof(T) * ldx, X, sizeof(T) * rows, sizeof(T) * rows, cols, hipMemcpyHostToDevice));
+  // the primitive the compressed fronts use (hs_compress.h): interpolative form, rank and interpolation from the orthogonalisation of
+  // the sketch rows in tournament-pivot order (lowrank_id_batch); HS_LR_QR=0: the LU-based factors of hs_lowrank.hip
+  static const bool lr_qr = !(getenv("HS_LR_QR") && getenv("HS_LR_QR")[0] == '0');
   LowRank<T> lr;
-  int st = lowrank_compress<T>(dX, ldx, (int)rows, (int)cols, atol, rtol, (int)kinit, (uint64_t)seed, 0, &lr);
+  int st;
+  if (lr_qr) {
+    LowRankJob<T> job{dX, ldx, (int)rows, (int)cols, (int)kinit, (uint64_t)seed, &lr, 0};
+    st = lowrank_id_batch<T>(&job, 1, atol, rtol, 0);
+  } else {
+    st = lowrank_compress<T>(dX, ldx, (int)rows, (int)cols, atol, rtol, (int)kinit, (uint64_t)seed, 0, &lr);
+  }
   if (st != 0) return st;
   *r_out = lr.r;
   if (lr.r > cap) {
     hs_set_error(HS_ERR_ARGUMENT, lr.r, "rank %d exceeds the output capacity %lld", lr.r, (long long)cap);
     return HS_ERR_ARGUMENT;
   }
-  std::vector<T> hL((size_t)lr.ldp * lr.k);
-  std::vector<int> rp(rows);
-  CK(hipMemcpy(hL.data(), lr.Lp, sizeof(T) * hL.size(), hipMemcpyDeviceToHost));
-  CK(hipMemcpy(rp.data(), lr.rperm, sizeof(int) * rows, hipMemcpyDeviceToHost));
-  for (int64_t i = 0; i < rows; ++i)
-    for (int64_t j = 0; j < lr.r; ++j) {
-      T v = (i == j) ? Scal<T>::one() : (i > j ? hL[(size_t)i + (size_t)j * lr.ldp] : Scal<T>::zero());
-      Cout[(size_t)rp[i] + (size_t)j * rows] = v;
-    }
+  if (lr.Cd) {
+    if (lr.r > 0) CK(hipMemcpy2D(Cout, sizeof(T) * rows, lr.Cd, sizeof(T) * lr.ldc, sizeof(T) * rows, lr.r, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<T> hL((size_t)lr.ldp * lr.k);
+    std::vector<int> rp(rows);
+    CK(hipMemcpy(hL.data(), lr.Lp, sizeof(T) * hL.size(), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(rp.data(), lr.rperm, sizeof(int) * rows, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < rows; ++i)
+      for (int64_t j = 0; j < lr.r; ++j) {
+        T v = (i == j) ? Scal<T>::one() : (i > j ? hL[(size_t)i + (size_t)j * lr.ldp] : Scal<T>::zero());
+        Cout[(size_t)rp[i] + (size_t)j * rows] = v;
+      }
+  }
   if (lr.r > 0) CK(hipMemcpy2D(Zout, sizeof(T) * lr.r, lr.Z, sizeof(T) * lr.ldz, sizeof(T) * lr.r, cols, hipMemcpyDeviceToHost));
   lowrank_free(lr);
   (void)hipFree(dX);

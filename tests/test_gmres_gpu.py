@@ -66,12 +66,16 @@ def test_native_gmres_arguments(hs):
 
     P = prepare(hs, (15, 15), kind="helmholtz", nmax=20, rhs="randn")
     F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0)
-    # an initial guess that is already the solution: zero iterations
+    # an initial guess: same behaviour as the mirror (the residual of the guess is the reference of `reltol`)
     import scipy.sparse.linalg as spla
 
-    xs = spla.splu(P["A"]).solve(P["b"])
-    x, c = gmres_native(P["A"], P["b"], Pr=F, reltol=1e-9, restart=30, maxiter=10, log=True, x0=xs)
-    assert c["iters"] == 0 and c["isconverged"]
+    x0 = spla.splu(P["A"]).solve(P["b"]) * (1 + 1e-3)
+    x, c = gmres_native(P["A"], P["b"], Pr=F, reltol=1e-6, restart=30, maxiter=10, log=True, x0=x0)
+    xm, cm = hs.gmres(P["A"], P["b"], Pr=F, reltol=1e-6, restart=30, maxiter=10, log=True, x0=x0)
+    assert c["iters"] == cm["iters"] and c["isconverged"] and relerr(x, xm) < 1e-8
+    # b = 0: nothing to do
+    x, c = gmres_native(P["A"], 0 * P["b"], Pr=F, reltol=1e-9, restart=30, maxiter=10, log=True)
+    assert c["iters"] == 0 and c["isconverged"] and not np.any(x)
     # a real factorization cannot precondition a complex system (MethodError in Julia)
     Pr = prepare(hs, (15, 15), kind="poisson", nmax=20, rhs="randn")
     Fr = hs.factor(Pr["A"], Pr["nd"], Pr["nd_loc"], swlevel=0)
