@@ -197,15 +197,55 @@ static BlockCache* global_cache() {
   static BlockCache* g = new BlockCache();
   return g;
 }
+// Pinned host staging blocks for descriptor uploads: a copy from pinned memory is asynchronous (ordered on the stream, no host
+// synchronisation), one from a pageable std::vector is not -- and the module uploads a few small descriptor lists per tree level.
+struct PinnedCache {
+  std::multimap<size_t, void*> free_;
+  std::mutex mu;
+};
+static PinnedCache* pinned_cache() {
+  static PinnedCache* g = new PinnedCache();
+  return g;
+}
 struct Pool {
   std::vector<std::pair<void*, size_t>> v;
+  std::vector<std::pair<void*, size_t>> hv;  // pinned host blocks (valid until clear(): the copies they feed have been waited for by then)
   BlockCache* cache = nullptr;
+  void* get_pinned(size_t bytes) {
+    size_t cls = 4096;
+    while (cls < bytes) cls <<= 1;
+    PinnedCache* pc = pinned_cache();
+    {
+      std::lock_guard<std::mutex> lk(pc->mu);
+      auto it = pc->free_.find(cls);
+      if (it != pc->free_.end()) {
+        void* p = it->second;
+        pc->free_.erase(it);
+        hv.push_back({p, cls});
+        return p;
+      }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      hs_set_error(HS_ERR_NOMEM, 0, "hipHostMalloc of %zu bytes failed (HSS module)", cls);
+      throw (int)HS_ERR_NOMEM;
+    }
+    hv.push_back({p, cls});
+    return p;
+  }
   Pool() = default;
   explicit Pool(BlockCache* c) : cache(c) {}
   Pool(const Pool&) = delete;
   Pool& operator=(const Pool&) = delete;
   ~Pool() { clear(); }
   void clear() {
+    if (!hv.empty()) {
+      PinnedCache* pc = pinned_cache();
+      std::lock_guard<std::mutex> lk(pc->mu);
+      for (auto& pr : hv) pc->free_.insert({pr.second, pr.first});
+      hv.clear();
+    }
     if (cache) {
       std::lock_guard<std::mutex> lk(cache->mu);
       for (auto& pr : v) {
@@ -315,6 +355,17 @@ struct HssT {
   }
 };
 
+// asynchronous on `s` through a pinned staging block that lives as long as `pool` does (every user synchronises `s` before its pool dies)
+template <class J>
+J* upload(Pool& pool, const std::vector<J>& v, hipStream_t s) {
+  J* d = pool.get<J>(std::max<size_t>(v.size(), 1));
+  if (v.empty()) return d;
+  const size_t bytes = sizeof(J) * v.size();
+  void* h = pool.get_pinned(bytes);
+  memcpy(h, v.data(), bytes);
+  HSS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+  return d;
+}
 template <class J>
 J* upload(Pool& pool, const std::vector<J>& v) {
   J* d = pool.get<J>(std::max<size_t>(v.size(), 1));
@@ -334,7 +385,7 @@ void run_rows(Pool& tmp, std::vector<RowJob<T>>& jobs, hipStream_t s) {
     }
   jobs.clear();
   if (live.empty()) return;
-  RowJob<T>* d = upload(tmp, live);
+  RowJob<T>* d = upload(tmp, live, s);
   for (size_t b = 0; b < live.size(); b += 32768) {
     const unsigned cnt = (unsigned)std::min<size_t>(32768, live.size() - b);
     hipLaunchKernelGGL(row_move_kernel<T>, dim3((mr + 63) / 64, (mc + 15) / 16, cnt), dim3(64), 0, s, (const RowJob<T>*)(d + b));
@@ -352,7 +403,7 @@ void run_subs(Pool& tmp, std::vector<SubJob<T>>& jobs, hipStream_t s) {
     }
   jobs.clear();
   if (live.empty()) return;
-  SubJob<T>* d = upload(tmp, live);
+  SubJob<T>* d = upload(tmp, live, s);
   for (size_t b = 0; b < live.size(); b += 32768) {
     const unsigned cnt = (unsigned)std::min<size_t>(32768, live.size() - b);
     hipLaunchKernelGGL(sub_gather_kernel<T>, dim3((mr + 63) / 64, (mc + 15) / 16, cnt), dim3(64), 0, s, (const SubJob<T>*)(d + b));
@@ -372,7 +423,7 @@ void run_gemms(Pool& tmp, std::vector<GemmProb<T>>& probs, int minus, hipStream_
     }
   probs.clear();
   if (live.empty()) return;
-  GemmProb<T>* d = upload(tmp, live);
+  GemmProb<T>* d = upload(tmp, live, s);
   for (size_t b = 0; b < live.size(); b += 32768) {
     const int cnt = (int)std::min<size_t>(32768, live.size() - b);
     launch_gemm_probs<T>(d + b, cnt, mM, mN, minus, s);
@@ -646,7 +697,11 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
   std::vector<SubJob<T>> subs;
   std::vector<GemmProb<T>> g;
   std::vector<std::vector<T*>> linv(nj), linvp(nj);  // one 32 x 32 slot per accepted block
+  static const bool qtime = getenv("HS_QR_TIMING") != nullptr;  // diagnostics: wall time of the phases (adds nothing: every step syncs anyway)
+  auto tq0 = std::chrono::steady_clock::now();
+  int nsteps = 0;
   for (;;) {
+    ++nsteps;
     auto each = [&](auto&& f) {
       for (int a = 0; a < nj; ++a)
         if (st[a].active) f(a, jobs[a], st[a], std::min(32, jobs[a].rmax - st[a].done));
@@ -686,7 +741,7 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
                               rtol, scale_floor, b, S.done == 0 ? 1 : 0});
     });
     run_gemms(tmp, g, 0, s);
-    CholJob<T>* dcj = upload(tmp, cj);
+    CholJob<T>* dcj = upload(tmp, cj, s);
     hipLaunchKernelGGL(chol_block_kernel<T>, dim3((unsigned)cj.size()), dim3(64), 0, s, (const CholJob<T>*)dcj);
     // how many candidates each job accepted
     HSS_HIP(hipMemcpyAsync(hacc.data(), dnacc, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, s));
@@ -726,6 +781,7 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     }
     // a rejected candidate above the threshold keeps the job going; one below it ends the job -- told apart by the next window: its first pivot is then <= tau
   }
+  auto tq1 = std::chrono::steady_clock::now();
   // ranks and d_0
   int maxblocks = 0;
   for (int a = 0; a < nj; ++a) {
@@ -774,6 +830,13 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     run_subs(tmp, back, s);
   }
   HSS_HIP(hipStreamSynchronize(s));
+  if (qtime) {
+    auto tq2 = std::chrono::steady_clock::now();
+    int mr = 0, mm = 0, mq = 0;
+    for (auto& J : jobs) { mr = std::max(mr, J.r); mm = std::max(mm, J.m); mq = std::max(mq, J.q); }
+    fprintf(stderr, "[hs qr] %d jobs (m <= %d, q <= %d, rank <= %d): %d windows %.2f ms, interpolation (%d block steps) %.2f ms\n", nj, mm, mq, mr, nsteps,
+            std::chrono::duration<double, std::milli>(tq1 - tq0).count(), maxblocks, std::chrono::duration<double, std::milli>(tq2 - tq1).count());
+  }
 }
 
 template <class T>
@@ -783,6 +846,15 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
   const int n = H.n;
   hipStream_t s = H.s;
   Pool tmp(global_cache());  // samples and everything else that dies with this attempt
+  static const bool vtime = getenv("HS_HSS_VERBOSE") != nullptr;  // diagnostics: wall time of every phase (adds synchronisations)
+  auto vt0 = std::chrono::steady_clock::now();
+  auto vlap = [&](const char* what, int lv) {
+    if (!vtime) return;
+    (void)hipStreamSynchronize(s);
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[hs hss]      n=%d k=%d level %d: %-34s %8.3f ms\n", n, k, lv, what, std::chrono::duration<double, std::milli>(now - vt0).count());
+    vt0 = now;
+  };
   H.keep.clear();
   build_tree(H, n, (int)H.opt.leafsize, (int)H.opt.first_split);
   H.k = k;
@@ -900,6 +972,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     run_rows(tmp, rows, s);
   }
 
+  vlap(bop ? "samples Op*Omega, Op^T*Psi (matrix-free)" : "samples A*Omega, Psi^T*A", 0);
   const int N = (int)nd.size();
   // local sample / test blocks of every node (leaf: rows lo:hi of Y / OP), global index of every local position
   std::vector<T*> Yl(N, nullptr), Ol(N, nullptr);
@@ -955,6 +1028,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       }
     }
     gather_A();
+    vlap("entry blocks (D / B12, B21)", lv);
     run_gemms(tmp, gemms, 1, s);
     // ---- b. row IDs of the sample blocks [Sr | Sc] (read in place: without Z the ID leaves its input alone) -----------------
     std::vector<LowRank<T>> lr(nj);
@@ -973,6 +1047,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     // that couples weakly (or not at all) is noise of the children's truncation, and relative to ITSELF noise has full rank
     const int st = lowrank_compress_batch<T>(jobs.data(), nj, std::max(H.opt.atol, H.opt.rtol * gscale) * lsc, H.opt.rtol * lsc, s, false);
     for (int a = 0; a < nj; ++a) gscale = std::max(gscale, lr[a].top);
+    vlap("pivot order (tournament LU of sketches)", lv);
     auto free_lr = [&]() {
       for (auto& q : lr) lowrank_free(q);
     };
@@ -1001,6 +1076,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
         throw;
       }
       for (int a = 0; a < nj; ++a) gscale_q = std::max(gscale_q, qj[a].top);
+      vlap("rank + interpolation (qr_refine)", lv);
     }
     bool enough = true;
     for (int a = 0; a < nj; ++a) {
@@ -1087,8 +1163,8 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
           st.tn = ts.size() - st.t0;
           steps.push_back(st);
         }
-        GemmProb<T>* dgp = upload(tmp, gp);
-        TsJob<T>* dts = upload(tmp, ts);
+        GemmProb<T>* dgp = upload(tmp, gp, s);
+        TsJob<T>* dts = upload(tmp, ts, s);
         for (const Step& st : steps) {
           if (st.gn > 0) launch_gemm_probs<T>(dgp + st.g0, (int)st.gn, maxR, st.mN, 1, s);
           if (st.tn > 0) hipLaunchKernelGGL(tsolve_block_kernel<T>, dim3((maxR + 63) / 64, (unsigned)st.tn), dim3(64), 0, s, (const TsJob<T>*)(dts + st.t0));
@@ -1115,7 +1191,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
         }
         fprintf(stderr, "[hs hss]      level %d: max |T_ij| = %.3g\n", lv, tmax);
       }
-      IdxJob* dij = upload(tmp, ij);
+      IdxJob* dij = upload(tmp, ij, s);
       hipLaunchKernelGGL(idx_compose_kernel, dim3((maxr + 63) / 64, (unsigned)ij.size()), dim3(64), 0, s, (const IdxJob*)dij);
       if (bop) {  // the matrix-free operator routes entry requests on the host: it needs the skeleton indices there
         for (int i : L) {
@@ -1165,6 +1241,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       throw;
     }
     free_lr();
+    vlap("skeletons handed to the parents", lv);
   }
   // root: couplings of its two children
   {
@@ -1462,7 +1539,7 @@ void alloc_front(Pool& pool, NodeDesc<T>& d, int ni, int nb, int node) {
 template <class T>
 void factor_batch(Pool& tmp, std::vector<NodeDesc<T>>& hd, hipStream_t s) {
   if (hd.empty()) return;
-  NodeDesc<T>* dn = upload(tmp, hd);
+  NodeDesc<T>* dn = upload(tmp, hd, s);
   int maxni = 0, maxnb = 0, maxm = 0;
   for (auto& d : hd) {
     maxni = std::max(maxni, d.ni);
@@ -1571,7 +1648,7 @@ void tri_solve_batch(Pool& tmp, std::vector<NodeDesc<T>>& hd, int q, bool lower,
   if (hd.empty()) return;
   int maxni = 0;
   for (auto& d : hd) maxni = std::max(maxni, d.ni);
-  NodeDesc<T>* dn = upload(tmp, hd);
+  NodeDesc<T>* dn = upload(tmp, hd, s);
   Profiler prof;
   Sched<T> sch{dn, (int)hd.size(), maxni, q, maxni, s, &prof, nullptr, nullptr};
   int P2 = HS_PB;
@@ -1806,55 +1883,73 @@ __global__ __launch_bounds__(256) void id_expand_kernel(const int* __restrict__ 
 
 template <class T>
 int lowrank_id_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s) {
-  // pivot order: tournament-pivoted LU of the sketches (its own rank estimate only sizes the sketch)
-  int st = lowrank_compress_batch<T>(jobs, njobs, atol, rtol, s, false, true);
-  if (st != 0) return st;
+  static const bool qtime = getenv("HS_QR_TIMING") != nullptr;
+  std::vector<LowRankJob<T>> todo(jobs, jobs + njobs);
+  std::vector<int> which(njobs);
+  for (int a = 0; a < njobs; ++a) which[a] = a;
   try {
-    Pool tmp(global_cache()), keep(global_cache());
-    std::vector<QrJob<T>> qj;
-    std::vector<int> idx;
-    for (int a = 0; a < njobs; ++a) {
-      LowRank<T>& o = *jobs[a].out;
-      if (o.rows <= 0 || o.cols <= 0 || !o.Y0) continue;
-      QrJob<T> q;
-      q.M = o.Y0;
-      q.ldm = o.ldp;
-      q.m = o.rows;
-      q.q = o.k;
-      q.p = o.rperm;
-      q.rmax = o.k;
-      q.atol_scale = std::sqrt((double)o.k);  // the sketch is not normalised: |row of X*Omega| ~ sqrt(k) |row of X|
-      qj.push_back(q);
-      idx.push_back(a);
-    }
-    qr_refine<T>(tmp, keep, qj, atol, rtol, 0.0, s);
-    std::vector<RowJob<T>> rows;
-    for (size_t b = 0; b < qj.size(); ++b) {
-      LowRankJob<T>& J = jobs[idx[b]];
-      LowRank<T>& o = *J.out;
-      const int r = qj[b].r;
-      o.r = r;
-      o.top = qj[b].top;
-      o.ldz = std::max(2, (r + 1) / 2 * 2);
-      o.ldc = std::max(2, (o.rows + 1) / 2 * 2);
-      if (hipMalloc((void**)&o.Z, sizeof(T) * ((size_t)o.ldz * J.cols + 32)) != hipSuccess ||
-          hipMalloc((void**)&o.Cd, sizeof(T) * ((size_t)o.ldc * std::max(r, 1) + 32)) != hipSuccess) {
-        hs_set_error(HS_ERR_NOMEM, 0, "hipMalloc of a low-rank factor (%d x %d) failed", r, J.cols);
-        return HS_ERR_NOMEM;
+    for (int pass = 0; !todo.empty(); ++pass) {
+      auto t0 = std::chrono::steady_clock::now();
+      // pivot order: tournament-pivoted LU of the sketches (its own rank estimate is not used: |u_jj| overestimates the residual norms)
+      int st = lowrank_compress_batch<T>(todo.data(), (int)todo.size(), atol, rtol, s, false, true);
+      if (st != 0) return st;
+      if (qtime) {
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "[hs qr] sketch + tournament-pivoted LU of %zu blocks: %.2f ms\n", todo.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       }
-      if (r > 0) {
-        rows.push_back(RowJob<T>{J.X, J.ldx, o.Z, o.ldz, o.rperm, r, J.cols, ROW_GATHER});  // Z = the skeleton rows of X
-        hipLaunchKernelGGL(id_expand_kernel<T>, dim3((o.rows + 255) / 256), dim3(256), 0, s, (const int*)o.rperm, (const T*)qj[b].Tm, qj[b].ldt, o.rows, r, o.Cd, o.ldc);
+      Pool tmp(global_cache()), keep(global_cache());
+      std::vector<QrJob<T>> qj;
+      std::vector<int> idx;
+      for (size_t a = 0; a < todo.size(); ++a) {
+        LowRank<T>& o = *todo[a].out;
+        if (o.rows <= 0 || o.cols <= 0 || !o.Y0) continue;
+        QrJob<T> q;
+        q.M = o.Y0;
+        q.ldm = o.ldp;
+        q.m = o.rows;
+        q.q = o.k;
+        q.p = o.rperm;
+        q.rmax = o.k;
+        q.atol_scale = std::sqrt((double)o.k);  // the sketch is not normalised: |row of X*Omega| ~ sqrt(k) |row of X|
+        qj.push_back(q);
+        idx.push_back((int)a);
       }
-    }
-    run_rows(tmp, rows, s);
-    HSS_HIP(hipStreamSynchronize(s));
-    for (int a = 0; a < njobs; ++a) {  // the packed LU and the sketch copy are not needed again
-      LowRank<T>& o = *jobs[a].out;
-      if (o.Lp) (void)hipFree(o.Lp);
-      if (o.Y0) (void)hipFree(o.Y0);
-      o.Lp = nullptr;
-      o.Y0 = nullptr;
+      qr_refine<T>(tmp, keep, qj, atol, rtol, 0.0, s);
+      std::vector<RowJob<T>> rows;
+      std::vector<LowRankJob<T>> again;
+      for (size_t b = 0; b < qj.size(); ++b) {
+        LowRankJob<T>& J = todo[idx[b]];
+        LowRank<T>& o = *J.out;
+        const int r = qj[b].r, kmax = std::min(J.rows, J.cols);
+        if (r + 8 > o.k && o.k < kmax) {  // the sketch was too narrow to see the end of the spectrum: once more with twice the width
+          LowRankJob<T> n = J;
+          n.kinit = std::min(2 * o.k, kmax);
+          lowrank_free(o);
+          again.push_back(n);
+          continue;
+        }
+        o.r = r;
+        o.top = qj[b].top;
+        o.ldz = std::max(2, (r + 1) / 2 * 2);
+        o.ldc = std::max(2, (o.rows + 1) / 2 * 2);
+        if (hipMalloc((void**)&o.Z, sizeof(T) * ((size_t)o.ldz * J.cols + 32)) != hipSuccess ||
+            hipMalloc((void**)&o.Cd, sizeof(T) * ((size_t)o.ldc * std::max(r, 1) + 32)) != hipSuccess) {
+          hs_set_error(HS_ERR_NOMEM, 0, "hipMalloc of a low-rank factor (%d x %d) failed", r, J.cols);
+          return HS_ERR_NOMEM;
+        }
+        if (r > 0) {
+          rows.push_back(RowJob<T>{J.X, J.ldx, o.Z, o.ldz, o.rperm, r, J.cols, ROW_GATHER});  // Z = the skeleton rows of X
+          hipLaunchKernelGGL(id_expand_kernel<T>, dim3((o.rows + 255) / 256), dim3(256), 0, s, (const int*)o.rperm, (const T*)qj[b].Tm, qj[b].ldt, o.rows, r, o.Cd, o.ldc);
+        }
+        // the packed LU and the sketch copy are not needed again
+        if (o.Lp) (void)hipFree(o.Lp);
+        if (o.Y0) (void)hipFree(o.Y0);
+        o.Lp = nullptr;
+        o.Y0 = nullptr;
+      }
+      run_rows(tmp, rows, s);
+      HSS_HIP(hipStreamSynchronize(s));
+      todo.swap(again);
     }
   } catch (int code) {
     return code;

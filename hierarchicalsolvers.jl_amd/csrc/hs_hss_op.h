@@ -113,7 +113,7 @@ void run_z_batched(Pool& tmp, std::vector<J>& jobs, K kernel, hipStream_t s) {
     }
   jobs.clear();
   if (live.empty()) return;
-  J* d = upload(tmp, live);
+  J* d = upload(tmp, live, s);
   for (size_t b = 0; b < live.size(); b += 32768) {
     const unsigned cnt = (unsigned)std::min<size_t>(32768, live.size() - b);
     kernel(dim3((mr + 63) / 64, (mc + 15) / 16, cnt), (const J*)(d + b));
@@ -142,9 +142,11 @@ struct IntArena {
     return at;
   }
   int* put(const std::vector<int>& v) { return put(v.data(), v.size()); }
-  void flush(hipStream_t s) {
-    if (!h.empty()) HSS_HIP(hipMemcpyAsync(d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, s));
-    HSS_HIP(hipStreamSynchronize(s));  // the source is a host vector that may be reused
+  void flush(Pool& pool, hipStream_t s) {  // asynchronous: staged through a pinned block owned by `pool`
+    if (h.empty()) return;
+    void* ph = pool.get_pinned(sizeof(int) * h.size());
+    memcpy(ph, h.data(), sizeof(int) * h.size());
+    HSS_HIP(hipMemcpyAsync(d, ph, sizeof(int) * h.size(), hipMemcpyHostToDevice, s));
   }
 };
 
@@ -273,10 +275,10 @@ void hss_getindex_batch(HssT<T>& H, const std::vector<GiJob<T>>& jobs) {
     drI[b] = ia.put(rI);
     drJ[b] = ia.put(rJ);
   }
-  ia.flush(s);
+  ia.flush(tmp, s);
   run_subs(tmp, subs, s);
   if (!bjobs.empty()) {
-    BasisJob<T>* dj = upload(tmp, bjobs);
+    BasisJob<T>* dj = upload(tmp, bjobs, s);
     for (size_t b0 = 0; b0 < bjobs.size(); b0 += 32768) {
       const unsigned cnt = (unsigned)std::min<size_t>(32768, bjobs.size() - b0);
       hipLaunchKernelGGL(basis_rows_kernel<T>, dim3((maxcnt + 63) / 64, (maxr + 15) / 16, cnt), dim3(64), 0, s, (const BasisJob<T>*)(dj + b0));
@@ -459,7 +461,7 @@ struct BlockOp {
       diag(g1, I1, J1, dI1, dJ1);
       diag(g2, I2, J2, dI2, dJ2);
     }
-    ia.flush(s);
+    ia.flush(tmp, s);
     if (H1 && !g1.empty()) {
       H1->s = s;
       hss_getindex_batch<T>(*H1, g1);

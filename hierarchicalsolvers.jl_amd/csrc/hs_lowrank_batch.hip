@@ -227,7 +227,7 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
       for (int j = 0; j < J.k; ++j)
         if (dg[j] > tau) r = j + 1;
       const int kmax = std::min(J.rows, J.cols);
-      if (r + 8 > J.k && J.k < kmax) {
+      if (!keep_sketch && r + 8 > J.k && J.k < kmax) {  // (with keep_sketch the caller judges the width from the refined rank)
         J.k = std::min(2 * J.k, kmax);
         next.push_back(todo[a]);
         (void)hipFree(Y[a]);

@@ -46,10 +46,11 @@ def test_compressed_ldiv_accuracy(hs, name, swlevel, swsize, tol):
     assert OL.maxrank(Fo) > 0
     # both are O(tol)-accurate preconditioners (the oracle truncates Abi/Aib by QRCP before D^-1 is applied, the
     # product truncates Abi*U^-1 / L^-1*P*Aib by a sketched LU): within 10x of each other or of the tolerance
-    assert e_gpu <= max(10 * e_orc, 100 * tol), (e_gpu, e_orc)
+    assert e_gpu <= max(4 * e_orc, 50 * tol), (e_gpu, e_orc)
     print(f"tol={tol:g} err(product)={e_gpu:.2e} err(oracle)={e_orc:.2e} maxrank {hs.maxrank(F)} / {OL.maxrank(Fo)}")
-    # ranks revealed by the two factorizations agree up to the slack of the rank rule
-    assert hs.maxrank(F) <= 2 * OL.maxrank(Fo) + 16
+    # ranks: the device orders the rows by a tournament-pivoted LU of the sketch and truncates on the residual norms of their
+    # orthogonalisation, the oracle on the |R_jj| of a column-pivoted QR: within 15 %
+    assert hs.maxrank(F) <= 1.15 * OL.maxrank(Fo) + 4
 
 
 @pytest.mark.parametrize("name,swlevel,swsize", CASES[:3])

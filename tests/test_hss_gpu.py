@@ -58,7 +58,7 @@ def test_compress_mul_ldiv_against_oracle(hs, complex_, n, leaf, tol):
     ro = HS.hssrank(HS.compress(A, leafsize=leaf, atol=tol, rtol=tol, kest=32, level_scale=0.5))
     # (the device detects ranks from the pivots of a sketched LU, the oracle from a pivoted QR: same slack as the low-rank
     # Gauss transforms, tests/test_compressed_gpu.py)
-    assert Hd.rank == HS.hssrank(Ho) and Hd.rank <= 2 * ro + 8, (Hd.rank, ro)
+    assert Hd.rank == HS.hssrank(Ho) and Hd.rank <= 1.15 * ro + 4, (Hd.rank, ro)
     rng = np.random.default_rng(5)
     X = rng.standard_normal((n, 3)) + (1j * rng.standard_normal((n, 3)) if complex_ else 0)
     # product: device kernels vs the oracle's matvec on the same generators (round-off only)

@@ -81,6 +81,6 @@ def test_schur_complement_as_hss_matrix(hs, name):
     x = np.arange(nb, dtype=float)
     assert np.allclose(H @ x, H.full() @ x)
     Ho = HS.compress(S, leafsize=16, atol=tol, rtol=tol, kest=16, level_scale=0.5)
-    assert H.rank <= 2 * HS.hssrank(Ho) + 16 and H.rank > 0
+    assert H.rank <= 1.15 * HS.hssrank(Ho) + 4 and H.rank > 0
     b = np.ones(nb, dtype=S.dtype)
     assert np.linalg.norm(S @ H.ldiv(b) - b) / np.linalg.norm(b) < 1e4 * tol
