@@ -76,7 +76,7 @@ EXPORTS = [
     "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free", "hs_node_schur_hss",
-    "hs_hss_offdiag", "hs_hss_bytes", "hs_hss_compress_blockop_d", "hs_hss_compress_blockop_z", "hs_hss_blockop_apply",
+    "hs_hss_offdiag", "hs_hss_bytes", "hs_hss_prune_leaves", "hs_hss_compatible", "hs_hss_depth", "hs_hss_compress_blockop_d", "hs_hss_compress_blockop_z", "hs_hss_blockop_apply",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_bisect_perm",
 ]
 
@@ -231,6 +231,12 @@ def lib():
     L.hs_hss_mul_t.restype = C.c_int
     L.hs_hss_child.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.hs_hss_child.restype = C.c_int
+    L.hs_hss_prune_leaves.argtypes = [vp, C.POINTER(vp)]
+    L.hs_hss_prune_leaves.restype = C.c_int
+    L.hs_hss_compatible.argtypes = [vp, vp]
+    L.hs_hss_compatible.restype = C.c_int
+    L.hs_hss_depth.argtypes = [vp]
+    L.hs_hss_depth.restype = i64
     L.hs_hss_offdiag.argtypes = [vp, C.c_int, vp, i64, vp, i64, C.c_int]
     L.hs_hss_offdiag.restype = C.c_int
     for f in (L.hs_hss_compress_blockop_d, L.hs_hss_compress_blockop_z):

@@ -2202,6 +2202,150 @@ static HssT<T>* child_impl(HssT<T>* P, int which) {
   for (int i = 0; i < (int)C->nd.size(); ++i) C->lev[C->nd[i].level].push_back(i);
   return C.release();
 }
+// `prune_leaves!(H)` of HssMatrices.jl as `_equilibrate_clusters` uses it (src/factorization.jl:143-168): every node whose two children are
+// leaves becomes a leaf itself -- D = [D_l  U_l B12 U_r^T; U_r B21 U_l^T  D_r], basis U = blkdiag(U_l, U_r) U_node in the interpolative form
+// P^T [I; T] (the skeleton of the node is a subset of its children's skeletons, so the identity rows are there already).  The result is a view:
+// it shares every untouched generator with H (H must outlive it) and owns the merged blocks.
+template <class T>
+static HssT<T>* prune_impl(HssT<T>* P) {
+  if (P->nd[0].left < 0) {
+    hs_set_error(HS_ERR_HSS_LEAF, 0, "One of the Schur complements turned into a leaf. Aborting.");  // factorization.jl:163-165
+    throw (int)HS_ERR_HSS_LEAF;
+  }
+  hipStream_t s = P->s;
+  auto& nd = P->nd;
+  const int N = (int)nd.size();
+  std::vector<char> merge(N, 0), gone(N, 0);
+  for (int i = 0; i < N; ++i)
+    if (nd[i].left >= 0 && nd[nd[i].left].left < 0 && nd[nd[i].right].left < 0) {
+      merge[i] = 1;
+      gone[nd[i].left] = gone[nd[i].right] = 1;
+    }
+  std::unique_ptr<HssT<T>> C(new HssT<T>());
+  C->n = P->n;
+  C->k = P->k;
+  C->opt = P->opt;
+  C->s = s;
+  C->own_stream = false;
+  C->perm = P->perm;  // shared
+  C->hinvperm = P->hinvperm;
+  C->hperm = P->hperm;
+  std::vector<int> nw(N, -1);
+  int cnt = 0;
+  for (int i = 0; i < N; ++i)
+    if (!gone[i]) nw[i] = cnt++;  // breadth-first order is preserved
+  Pool tmp(global_cache());
+  std::vector<GemmProb<T>> g1, g2;
+  std::vector<SubJob<T>> subs;
+  for (int i = 0; i < N; ++i) {
+    if (gone[i]) continue;
+    HNode<T> y = nd[i];  // shares the device pointers
+    y.parent = y.parent >= 0 ? nw[y.parent] : -1;
+    y.has_front = false;
+    memset(&y.fd, 0, sizeof y.fd);
+    y.hinvp.clear();
+    y.NTm = y.DTt = y.B12t = y.B21t = nullptr;
+    if (!merge[i]) {
+      if (y.left >= 0) {
+        y.left = nw[y.left];
+        y.right = nw[y.right];
+      }
+      C->nd.push_back(y);
+      continue;
+    }
+    HNode<T>&l = nd[nd[i].left], &r = nd[nd[i].right];
+    const int ml = l.m, mr = r.m, m = ml + mr, rl = l.r, rr = r.r;
+    y.left = y.right = -1;
+    y.B12 = y.B21 = nullptr;
+    y.ldd = ev(m);
+    y.D = C->keep.template get<T>((size_t)y.ldd * m);
+    // D_l, D_r on the diagonal; U_l B12 U_r^T and U_r B21 U_l^T off it
+    subs.push_back(SubJob<T>{l.D, l.ldd, nullptr, nullptr, 0, 0, ml, ml, y.D, y.ldd, 0});
+    subs.push_back(SubJob<T>{r.D, r.ldd, nullptr, nullptr, 0, 0, mr, mr, y.D + ml + (size_t)ml * y.ldd, y.ldd, 0});
+    T* Ul = tmp.get<T>((size_t)ev(ml) * std::max(rl, 1));
+    T* Ur = tmp.get<T>((size_t)ev(mr) * std::max(rr, 1));
+    hss_basis<T>(*P, nd[i].left, Ul, ev(ml));
+    hss_basis<T>(*P, nd[i].right, Ur, ev(mr));
+    T* UrT = tmp.get<T>((size_t)ev(rr) * mr);
+    T* UlT = tmp.get<T>((size_t)ev(rl) * ml);
+    subs.push_back(SubJob<T>{Ur, ev(mr), nullptr, nullptr, 0, 0, mr, rr, UrT, ev(rr), 1});
+    subs.push_back(SubJob<T>{Ul, ev(ml), nullptr, nullptr, 0, 0, ml, rl, UlT, ev(rl), 1});
+    T* t12 = tmp.get<T>((size_t)ev(ml) * std::max(rr, 1));
+    T* t21 = tmp.get<T>((size_t)ev(mr) * std::max(rl, 1));
+    HSS_HIP(hipMemsetAsync(t12, 0, sizeof(T) * (size_t)ev(ml) * std::max(rr, 1), s));
+    HSS_HIP(hipMemsetAsync(t21, 0, sizeof(T) * (size_t)ev(mr) * std::max(rl, 1), s));
+    HSS_HIP(hipMemset2DAsync(y.D + (size_t)ml * y.ldd, sizeof(T) * y.ldd, 0, sizeof(T) * ml, mr, s));
+    HSS_HIP(hipMemset2DAsync(y.D + ml, sizeof(T) * y.ldd, 0, sizeof(T) * mr, ml, s));
+    g1.push_back(GemmProb<T>{Ul, nd[i].B12, t12, ml, rr, rl, ev(ml), nd[i].ld12, ev(ml)});
+    g1.push_back(GemmProb<T>{Ur, nd[i].B21, t21, mr, rl, rr, ev(mr), nd[i].ld21, ev(mr)});
+    g2.push_back(GemmProb<T>{t12, UrT, y.D + (size_t)ml * y.ldd, ml, mr, rr, ev(ml), ev(rr), y.ldd});
+    g2.push_back(GemmProb<T>{t21, UlT, y.D + ml, mr, ml, rl, ev(mr), ev(rl), y.ldd});
+    if (i != 0) {
+      // the node's basis over the merged leaf: E = blkdiag(U_l, U_r) U_node; its skeleton rows are identity rows of E
+      const int rk = nd[i].r;
+      std::vector<int> pp(nd[i].m), pl(ml), pr(mr);
+      HSS_HIP(hipMemcpy(pp.data(), nd[i].p, sizeof(int) * nd[i].m, hipMemcpyDeviceToHost));
+      HSS_HIP(hipMemcpy(pl.data(), l.p, sizeof(int) * ml, hipMemcpyDeviceToHost));
+      HSS_HIP(hipMemcpy(pr.data(), r.p, sizeof(int) * mr, hipMemcpyDeviceToHost));
+      std::vector<int> np(m);
+      std::vector<char> isk(m, 0);
+      for (int a = 0; a < rk; ++a) {
+        const int q = pp[a];  // position in [sk_l; sk_r]
+        const int loc = q < rl ? pl[q] : ml + pr[q - rl];
+        np[a] = loc;
+        isk[loc] = 1;
+      }
+      int at = rk;
+      for (int a = 0; a < m; ++a)
+        if (!isk[a]) np[at++] = a;
+      T* E = tmp.get<T>((size_t)ev(m) * std::max(rk, 1));
+      hss_basis<T>(*P, i, E, ev(m));
+      y.m = m;
+      y.p = C->keep.template get<int>(m);
+      HSS_HIP(hipMemcpy(y.p, np.data(), sizeof(int) * m, hipMemcpyHostToDevice));
+      y.ldt = ev(m - rk);
+      y.ldtt = ev(rk);
+      y.Tm = C->keep.template get<T>((size_t)y.ldt * std::max(rk, 1));
+      y.Tt = C->keep.template get<T>((size_t)y.ldtt * std::max(m - rk, 1));
+      subs.push_back(SubJob<T>{E, ev(m), y.p + rk, nullptr, 0, 0, m - rk, rk, y.Tm, y.ldt, 0});
+      subs.push_back(SubJob<T>{E, ev(m), y.p + rk, nullptr, 0, 0, m - rk, rk, y.Tt, y.ldtt, 1});
+      // sk (global indices of the skeleton) is unchanged: shared with H
+    } else {
+      y.m = m;
+    }
+    C->nd.push_back(y);
+  }
+  run_gemms(tmp, g1, 0, s);
+  run_gemms(tmp, g2, 0, s);
+  run_subs(tmp, subs, s);
+  HSS_HIP(hipStreamSynchronize(s));
+  C->nlev = 0;
+  for (auto& x : C->nd) C->nlev = std::max(C->nlev, x.level + 1);
+  C->lev.assign(C->nlev, {});
+  for (int i = 0; i < (int)C->nd.size(); ++i) C->lev[C->nd[i].level].push_back(i);
+  for (auto& x : C->nd)  // offsets inside the parents' local vectors (left child first)
+    if (x.parent >= 0) x.off_in_parent = (&x == &C->nd[C->nd[x.parent].left]) ? 0 : C->nd[C->nd[x.parent].left].r;
+  return C.release();
+}
+extern "C" int hs_hss_prune_leaves(hs_hss* H, hs_hss** out) {
+  if (!H || !out) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  HSS_GUARD(*out = H->is_complex ? new hs_hss{1, prune_impl<cplx>(HZ(H))} : new hs_hss{0, prune_impl<double>(HD(H))});
+}
+// `compatible(cl1, cl2)`: the two cluster trees have the same shape (what HSS-by-HSS arithmetic needs of its operands)
+template <class T>
+static int same_shape(const HssT<T>* A, int a, const HssT<T>* B, int b) {
+  const bool la = A->nd[a].left < 0, lb = B->nd[b].left < 0;
+  if (la != lb) return 0;
+  if (la) return 1;
+  return same_shape(A, A->nd[a].left, B, B->nd[b].left) && same_shape(A, A->nd[a].right, B, B->nd[b].right);
+}
+extern "C" int hs_hss_compatible(const hs_hss* A, const hs_hss* B) {
+  if (!A || !B || A->is_complex != B->is_complex) return 0;
+  return A->is_complex ? same_shape(HZ(A), 0, HZ(B), 0) : same_shape(HD(A), 0, HD(B), 0);
+}
+extern "C" int64_t hs_hss_depth(const hs_hss* H) { return H ? HSS_DISPATCH(H, HD(H)->nlev, HZ(H)->nlev) : 0; }
+
 extern "C" int hs_hss_child(hs_hss* H, int which, hs_hss** out) {
   if (!H || !out || which < 0 || which > 2) return HS_ERR_ARGUMENT;
   *out = nullptr;

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["HssMatrix", "compress", "compress_lowrank_update", "randcompress_adaptive", "hssrank", "bisection_cluster", "SparseDevice", "BlockOperator"]
+__all__ = ["HssMatrix", "compress", "compress_lowrank_update", "randcompress_adaptive", "hssrank", "bisection_cluster", "SparseDevice", "BlockOperator", "equilibrate_clusters"]
 
 
 def bisection_cluster(n, leafsize=64):
@@ -151,6 +151,21 @@ class HssMatrix:
         Z = np.zeros((nb, max(rb, 1)), dtype=self.dtype)   # column-major rb x nb
         _lib.check(self.L.hs_hss_offdiag(self._h, int(which), Cm.ctypes.data_as(C.c_void_p), na, Z.ctypes.data_as(C.c_void_p), max(rb, 1), 0))
         return Cm.T[:, :rb].copy(), Z.T[:rb].copy()
+
+    @property
+    def depth(self):
+        return int(self.L.hs_hss_depth(self._h))
+
+    def prune_leaves(self):
+        """``prune_leaves!``: every node whose two children are leaves becomes a leaf; the same matrix on a shallower tree (a view sharing the
+        untouched generators)."""
+        h = C.c_void_p()
+        _lib.check(self.L.hs_hss_prune_leaves(self._h, C.byref(h)))
+        return HssMatrix(h, self.is_complex, parent=self)
+
+    def compatible(self, other):
+        """``compatible(cluster(self), cluster(other))``: the two cluster trees have the same shape."""
+        return bool(self.L.hs_hss_compatible(self._h, other._h))
 
     def view(self):
         """All of ``H`` as a view in cluster-tree order (``H``'s own permutation dropped); shares the generators."""
@@ -324,3 +339,27 @@ class BlockOperator:
         H = HssMatrix(h, self.is_complex)
         H._operator = self  # the diagonal blocks are only read during the compression, but keep the inputs alive for inspection
         return H
+
+
+def equilibrate_clusters(S1, S2, verbose=False):
+    """``_equilibrate_clusters(S1, S2)`` (factorization.jl:143-168): prune the leaves of the deeper of ``S1.A11`` / ``S2.A11`` (of both at equal
+    depth) until their cluster trees are compatible; returns the two diagonal blocks.  Raises the reference's error when one of them turns
+    into a leaf.  The device elimination does not need it (every compression samples an operator); provided for HSS-by-HSS hosts."""
+    A1, A2 = S1.block(0), S2.block(0)
+    while not A1.compatible(A2):
+        d1, d2 = A1.depth, A2.depth
+        if d1 > d2:
+            if verbose:
+                print("Pruning clusters of node 1")
+            A1 = A1.prune_leaves()
+        elif d1 < d2:
+            if verbose:
+                print("Pruning clusters of node 2")
+            A2 = A2.prune_leaves()
+        else:
+            if verbose:
+                print("Pruning both clusters")
+            A1, A2 = A1.prune_leaves(), A2.prune_leaves()
+        if A1.num_nodes == 1 or A2.num_nodes == 1:
+            raise RuntimeError("One of the Schur complements turned into a leaf. Aborting.")
+    return A1, A2

@@ -131,6 +131,16 @@ int hs_hss_compress_blockop_z(const hs_hss_blockop* op, const double* C, int64_t
 /* Y = Op*X (trans != 0: Op^T*X) on device blocks of nrhs columns, in the operator's index order */
 int hs_hss_blockop_apply(const hs_hss_blockop* op, int is_complex, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int trans, void* stream);
 
+/* `prune_leaves!`, `compatible`, `depth` -- the operations of `_equilibrate_clusters` (src/factorization.jl:143-168), which makes the cluster trees
+ * of the two children's `S.A11` structurally equal before HSS-by-HSS arithmetic.  hs_hss_prune_leaves: every node whose two children are leaves
+ * becomes a leaf (D = [D_l  U_l B12 U_r^T; U_r B21 U_l^T  D_r]; its basis re-expressed over the merged leaf); the result is a view that shares
+ * the untouched generators of H (H must outlive it) and represents the SAME matrix.  HS_ERR_HSS_LEAF when H is a single leaf (:163-165).
+ * hs_hss_compatible: 1 when the two trees have the same shape.  The elimination itself never needs them here (every compression samples an
+ * operator, hs_mffront.h); they are provided for hosts that do HSS-by-HSS arithmetic on the handed-over Schur complements. */
+int hs_hss_prune_leaves(hs_hss* H, hs_hss** out);
+int hs_hss_compatible(const hs_hss* A, const hs_hss* B);
+int64_t hs_hss_depth(const hs_hss* H); /* levels of the cluster tree (1 = a single leaf) */
+
 /* ULV-type elimination of the HSS matrix (once), then B <- H^-1 B in place */
 int hs_hss_factor(hs_hss* H);
 int hs_hss_ldiv(hs_hss* H, double* B, int64_t ldb, int64_t nrhs, int where);

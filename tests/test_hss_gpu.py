@@ -300,3 +300,35 @@ def test_expanded_bases_and_offdiagonal_generators(hs, complex_):
     assert Uk.shape == (d["hi"] - d["lo"], d["r"])
     with pytest.raises(ValueError):
         H.basis(0)
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_prune_leaves_and_equilibrate_clusters(hs, complex_):
+    """`prune_leaves!` / `compatible` / `_equilibrate_clusters` (src/factorization.jl:143-168): pruning merges the deepest leaves without
+    changing the matrix the generators represent; two Schur complements of different depth end up on compatible trees."""
+    n = 700
+    A = kernel_matrix(n, complex_)
+    perm = np.random.default_rng(3).permutation(n)
+    H = hs.hss.compress(A, leafsize=40, atol=1e-9, rtol=1e-9, kest=48, perm=perm)
+    F0 = H.full()
+    Hp = H.prune_leaves()
+    assert Hp.depth == H.depth - 1 and Hp.num_nodes < H.num_nodes
+    assert np.linalg.norm(Hp.full() - F0) <= 1e-12 * np.linalg.norm(F0)  # the SAME matrix, leaf blocks formed from the generators
+    I, J = np.arange(0, n, 7), np.arange(3, n, 11)
+    assert np.linalg.norm(Hp.getindex(I, J) - F0[np.ix_(I, J)]) <= 1e-11 * np.linalg.norm(F0)
+    b = np.random.default_rng(4).standard_normal(n) + (1j if complex_ else 0)
+    assert np.linalg.norm(Hp.ldiv(b) - np.linalg.solve(F0, b)) <= 1e-8 * np.linalg.norm(b)
+    Hpp = Hp.prune_leaves()
+    assert Hpp.depth == H.depth - 2 and np.linalg.norm(Hpp.full() - F0) <= 1e-12 * np.linalg.norm(F0)
+    assert H.compatible(H) and not H.compatible(Hp)
+    # two "Schur complements" with the forced [int | bnd] split whose A11 blocks have different depths
+    S1 = hs.hss.compress(kernel_matrix(900, complex_), hs.hss.bisection_cluster((640, 900), leafsize=40), atol=1e-8, rtol=1e-8, kest=48)
+    S2 = hs.hss.compress(kernel_matrix(500, complex_), hs.hss.bisection_cluster((160, 500), leafsize=40), atol=1e-8, rtol=1e-8, kest=48)
+    assert not S1.block(0).compatible(S2.block(0))
+    A1, A2 = hs.hss.equilibrate_clusters(S1, S2)
+    assert A1.compatible(A2) and A1.shape == (640, 640) and A2.shape == (160, 160)
+    assert np.linalg.norm(A1.full() - S1.block(0).full()) <= 1e-12 * np.linalg.norm(A1.full())
+    # a matrix that is a single leaf cannot be pruned: the reference's error
+    H1 = hs.hss.compress(kernel_matrix(30, complex_), leafsize=64)
+    with pytest.raises(RuntimeError, match="turned into a leaf"):
+        H1.prune_leaves()
