@@ -163,7 +163,9 @@ def metric_workload(hs, hsdist, dev, name, swlevel, tol, steps):
     }
     # the scenario's acceptance number: right-preconditioned GMRES(30) to 1e-8 with this factorization (test/rungmres.jl:47-48)
     try:
-        from hierarchicalsolvers_jl_amd import gmres as hsg
+        import importlib
+
+        hsg = importlib.import_module("hierarchicalsolvers_jl_amd.gmres")  # (the package attribute `gmres` is the function)
 
         t0 = time.perf_counter()
         xg, hist = hsg.gmres_device(Ap, bd0, S, reltol=1e-8, restart=30, maxiter=30)
