@@ -2315,9 +2315,9 @@ static HssT<T>* prune_impl(HssT<T>* P) {
     }
     C->nd.push_back(y);
   }
+  run_subs(tmp, subs, s);  // diagonal blocks, transposed bases, interpolation rows
   run_gemms(tmp, g1, 0, s);
   run_gemms(tmp, g2, 0, s);
-  run_subs(tmp, subs, s);
   HSS_HIP(hipStreamSynchronize(s));
   C->nlev = 0;
   for (auto& x : C->nd) C->nlev = std::max(C->nlev, x.level + 1);
