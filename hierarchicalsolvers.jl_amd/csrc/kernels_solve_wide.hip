@@ -11,8 +11,6 @@
 #include "hs_common.h"
 
 #define HS_SW 256  // columns per launch
-// HS_SWR (template parameter): row blocks of 256 per workgroup -- the redundant y = inv256 * w of a workgroup (up to 256 KB from L2) is
-// shared by HS_SWR * 512 KB of panel traffic; the launcher picks 4 / 2 / 1 so that a launch still has >= 1024 workgroups when it can
 
 // ------------------------------------------------------------------------------------------------
 // inverses of the 256 x 256 diagonal blocks.  grid.x = (256-block, block column j of it), grid.y = front, grid.z = L / U
@@ -90,7 +88,7 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
 }
 
 // forward: y_blk = L[blk,blk]^-1 * w_blk ; rows below -= L[:, blk] * y_blk   (rows >= ni are the Abi*U^-1 rows: they update rhs[bnd])
-template <class T, int HS_SWR>
+template <class T>
 __global__ __launch_bounds__(256) void fwd_wide_kernel(const SolveNode<T>* __restrict__ nodes, int blk, T* __restrict__ w, T* __restrict__ y,
                                                        T* __restrict__ b) {
   const SolveNode<T> nd = nodes[blockIdx.y];
@@ -98,7 +96,7 @@ __global__ __launch_bounds__(256) void fwd_wide_kernel(const SolveNode<T>* __res
   if (c0 >= nd.ni) return;
   const int wl = min(HS_SW, nd.ni - c0);
   const int r0 = c0 + wl;
-  if (blockIdx.x > 0 && (int)blockIdx.x * 256 * HS_SWR >= nd.mrows - r0) return;
+  if (blockIdx.x > 0 && (int)blockIdx.x * 256 >= nd.mrows - r0) return;
   __shared__ T s_w[HS_SW];
   __shared__ T s_y[HS_SW];
   const int t = threadIdx.x;
@@ -116,43 +114,28 @@ __global__ __launch_bounds__(256) void fwd_wide_kernel(const SolveNode<T>* __res
   }
   __syncthreads();
   if (blockIdx.x == 0 && t < wl) y[nd.woff + c0 + t] = s_y[t];
-  const int rb = r0 + blockIdx.x * 256 * HS_SWR + t;
-  const T* a0 = nd.LF + (size_t)c0 * nd.ldl;
-  T acc[HS_SWR];
-  int rr[HS_SWR];
-#pragma unroll
-  for (int u = 0; u < HS_SWR; ++u) {
-    acc[u] = Scal<T>::zero();
-    rr[u] = min(rb + 256 * u, nd.mrows - 1);  // clamped: rows past the end repeat the last one and are not stored
-  }
-#pragma unroll 4
-  for (int j = 0; j < wl; ++j) {
-    const T yj = s_y[j];
-    const T* col = a0 + (size_t)j * nd.ldl;
-#pragma unroll
-    for (int u = 0; u < HS_SWR; ++u) acc[u] = Scal<T>::fma(col[rr[u]], yj, acc[u]);
-  }
-#pragma unroll
-  for (int u = 0; u < HS_SWR; ++u) {
-    const int r = rb + 256 * u;
-    if (r >= nd.mrows) break;
-    if (r < nd.ni) {
-      w[nd.woff + r] = w[nd.woff + r] - acc[u];
-    } else {
-      const int g = nd.fidx[r];
-      b[g] = b[g] - acc[u];
-    }
+  const int r = r0 + blockIdx.x * 256 + t;
+  if (r >= nd.mrows) return;
+  const T* a = nd.LF + (size_t)r + (size_t)c0 * nd.ldl;
+  T acc = Scal<T>::zero();
+#pragma unroll 8
+  for (int j = 0; j < wl; ++j) acc = Scal<T>::fma(a[(size_t)j * nd.ldl], s_y[j], acc);
+  if (r < nd.ni) {
+    w[nd.woff + r] = w[nd.woff + r] - acc;
+  } else {
+    const int g = nd.fidx[r];
+    b[g] = b[g] - acc;
   }
 }
 
 // backward: x_blk = U[blk,blk]^-1 * w_blk ; rows above -= U[:, blk] * x_blk
-template <class T, int HS_SWR>
+template <class T>
 __global__ __launch_bounds__(256) void bwd_wide_kernel(const SolveNode<T>* __restrict__ nodes, int blk, T* __restrict__ w, T* __restrict__ x) {
   const SolveNode<T> nd = nodes[blockIdx.y];
   const int c0 = blk * HS_SW;
   if (c0 >= nd.ni) return;
   const int wl = min(HS_SW, nd.ni - c0);
-  if (blockIdx.x > 0 && (int)blockIdx.x * 256 * HS_SWR >= c0) return;
+  if (blockIdx.x > 0 && (int)blockIdx.x * 256 >= c0) return;
   __shared__ T s_w[HS_SW];
   __shared__ T s_x[HS_SW];
   const int t = threadIdx.x;
@@ -169,29 +152,13 @@ __global__ __launch_bounds__(256) void bwd_wide_kernel(const SolveNode<T>* __res
   }
   __syncthreads();
   if (blockIdx.x == 0 && t < wl) x[nd.woff + c0 + t] = s_x[t];
-  if (c0 <= 0) return;
-  const int rb = blockIdx.x * 256 * HS_SWR + t;
-  const T* a0 = nd.LF + (size_t)c0 * nd.ldl;
-  T acc[HS_SWR];
-  int rr[HS_SWR];
-#pragma unroll
-  for (int u = 0; u < HS_SWR; ++u) {
-    acc[u] = Scal<T>::zero();
-    rr[u] = min(rb + 256 * u, c0 - 1);
-  }
-#pragma unroll 4
-  for (int j = 0; j < wl; ++j) {
-    const T xj = s_x[j];
-    const T* col = a0 + (size_t)j * nd.ldl;
-#pragma unroll
-    for (int u = 0; u < HS_SWR; ++u) acc[u] = Scal<T>::fma(col[rr[u]], xj, acc[u]);
-  }
-#pragma unroll
-  for (int u = 0; u < HS_SWR; ++u) {
-    const int r = rb + 256 * u;
-    if (r >= c0) break;
-    w[nd.woff + r] = w[nd.woff + r] - acc[u];
-  }
+  const int r = blockIdx.x * 256 + t;
+  if (r >= c0) return;
+  const T* a = nd.LF + (size_t)r + (size_t)c0 * nd.ldl;
+  T acc = Scal<T>::zero();
+#pragma unroll 8
+  for (int j = 0; j < wl; ++j) acc = Scal<T>::fma(a[(size_t)j * nd.ldl], s_x[j], acc);
+  w[nd.woff + r] = w[nd.woff + r] - acc;
 }
 
 template <class T>
@@ -212,25 +179,15 @@ template <class T>
 void launch_fwd_wide(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w, T* y, T* b, hipStream_t s) {
   if (nbatch <= 0) return;
   const int rows = maxm - blk * HS_SW;
-  const int g1 = rows > 0 ? (rows + 255) / 256 : 1;
-  if ((long long)(g1 / 4) * nbatch >= 1024)
-    hipLaunchKernelGGL((fwd_wide_kernel<T, 4>), dim3((g1 + 3) / 4, nbatch), dim3(256), 0, s, dn, blk, w, y, b);
-  else if ((long long)(g1 / 2) * nbatch >= 1024)
-    hipLaunchKernelGGL((fwd_wide_kernel<T, 2>), dim3((g1 + 1) / 2, nbatch), dim3(256), 0, s, dn, blk, w, y, b);
-  else
-    hipLaunchKernelGGL((fwd_wide_kernel<T, 1>), dim3(g1, nbatch), dim3(256), 0, s, dn, blk, w, y, b);
+  const int gx = rows > 0 ? (rows + 255) / 256 : 1;
+  hipLaunchKernelGGL(fwd_wide_kernel<T>, dim3(gx, nbatch), dim3(256), 0, s, dn, blk, w, y, b);
 }
 template <class T>
 void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s) {
   if (nbatch <= 0) return;
   const int rows = blk * HS_SW;
-  const int g1 = rows > 0 ? (rows + 255) / 256 : 1;
-  if ((long long)(g1 / 4) * nbatch >= 1024)
-    hipLaunchKernelGGL((bwd_wide_kernel<T, 4>), dim3((g1 + 3) / 4, nbatch), dim3(256), 0, s, dn, blk, w, x);
-  else if ((long long)(g1 / 2) * nbatch >= 1024)
-    hipLaunchKernelGGL((bwd_wide_kernel<T, 2>), dim3((g1 + 1) / 2, nbatch), dim3(256), 0, s, dn, blk, w, x);
-  else
-    hipLaunchKernelGGL((bwd_wide_kernel<T, 1>), dim3(g1, nbatch), dim3(256), 0, s, dn, blk, w, x);
+  const int gx = rows > 0 ? (rows + 255) / 256 : 1;
+  hipLaunchKernelGGL(bwd_wide_kernel<T>, dim3(gx, nbatch), dim3(256), 0, s, dn, blk, w, x);
 }
 int hs_solve_wide_cols() { return HS_SW; }
 
