@@ -531,29 +531,31 @@ __device__ inline cplx from_real<cplx>(double a) { return {a, 0.0}; }
 // Gram matrix resolves reliably in double precision is d_k / |w_k| >~ 1e-8).  Rejected candidates stay next in line: the following
 // window orthogonalises them against the rows accepted here before judging them again.
 #define HS_CHOL_COND 1e-5
+#define HS_QW 64  // candidates per window (rows orthogonalised per step): one wave factors their HS_QW x HS_QW Gram matrix in LDS
 template <class T>
 __global__ __launch_bounds__(64) void chol_block_kernel(const CholJob<T>* __restrict__ jobs) {
   const CholJob<T> j = jobs[blockIdx.x];
-  __shared__ T g[32][33];
-  __shared__ T li[32][33];
-  __shared__ int perm[32];
+  constexpr int W = HS_QW, LD = HS_QW + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
+  T* g = reinterpret_cast<T*>(chol_smem);  // W x LD
+  T* li = g + W * LD;                      // W x LD
+  int* perm = reinterpret_cast<int*>(li + W * LD);
+  int* oldp = perm + W;
   __shared__ int s_piv;
   __shared__ double s_dk;
   __shared__ int s_nacc;
   const int t = threadIdx.x, b = j.b;
-  if (t < 32) {
-    for (int c = 0; c < 32; ++c) g[t][c] = (t < b && c < b) ? j.G[(size_t)t + (size_t)c * 32] : Scal<T>::zero();
-    perm[t] = t;
-  }
+  for (int c = 0; c < W; ++c) g[t * LD + c] = (t < b && c < b) ? j.G[(size_t)t + (size_t)c * W] : Scal<T>::zero();
+  perm[t] = t;
   if (t == 0) s_nacc = 0;
   __syncthreads();
   double top = j.first ? 0.0 : *j.top, d0 = 0.0, tau = 0.0;
   for (int k = 0; k < b; ++k) {
     if (t == 0) {  // largest remaining diagonal entry
       int best = k;
-      double bv = real_of(g[k][k]);
+      double bv = real_of(g[k * LD + k]);
       for (int i = k + 1; i < b; ++i) {
-        const double v = real_of(g[i][i]);
+        const double v = real_of(g[i * LD + i]);
         if (v > bv) { bv = v; best = i; }
       }
       s_piv = best;
@@ -568,59 +570,51 @@ __global__ __launch_bounds__(64) void chol_block_kernel(const CholJob<T>* __rest
       tau = fmax(j.atol, j.rtol * fmax(top, j.scale_floor));
     }
     if (!(dk > tau) || !(dk > HS_CHOL_COND * d0) || !(dk > 0.0)) break;  // uniform: every thread sees the same dk
-    // symmetric swap k <-> pv of the (lower-triangle stored) matrix and of the finished columns
+    // symmetric swap k <-> pv of the full square copy (both triangles are maintained) and of the finished columns
     if (pv != k && t < b) {
       if (t == 0) { const int q = perm[k]; perm[k] = perm[pv]; perm[pv] = q; }
-      // row/column swap on the full square copy: keep it simple, the matrix is 32 x 32 (both triangles are maintained)
-      const T a = g[t][k], c = g[t][pv];
-      g[t][k] = c;
-      g[t][pv] = a;
+      const T a = g[t * LD + k], c = g[t * LD + pv];
+      g[t * LD + k] = c;
+      g[t * LD + pv] = a;
     }
     __syncthreads();
     if (pv != k && t < b) {
-      const T a = g[k][t], c = g[pv][t];
-      g[k][t] = c;
-      g[pv][t] = a;
+      const T a = g[k * LD + t], c = g[pv * LD + t];
+      g[k * LD + t] = c;
+      g[pv * LD + t] = a;
     }
     __syncthreads();
-    if (t < b && t >= k) g[t][k] = t == k ? from_real<T>(dk) : g[t][k] / from_real<T>(dk);
+    if (t < b && t >= k) g[t * LD + k] = t == k ? from_real<T>(dk) : g[t * LD + k] / from_real<T>(dk);
     __syncthreads();
     if (t < b && t > k)
-      for (int c = k + 1; c < b; ++c) {  // trailing update of the whole square (Hermitian: g[t][c] -= l_t * conj(l_c))
-        g[t][c] = Scal<T>::fnma(g[t][k], conj_of(g[c][k]), g[t][c]);
-      }
+      for (int c = k + 1; c < b; ++c) g[t * LD + c] = Scal<T>::fnma(g[t * LD + k], conj_of(g[c * LD + k]), g[t * LD + c]);  // Hermitian trailing update
     if (t == 0) s_nacc = k + 1;
     __syncthreads();
   }
   __syncthreads();
   const int na = s_nacc;
   // inverse of the accepted lower-triangular factor: thread c solves L x = e_c
-  if (t < 32)
-    for (int i = 0; i < 32; ++i) li[i][t] = Scal<T>::zero();
+  for (int i = 0; i < W; ++i) li[i * LD + t] = Scal<T>::zero();
   __syncthreads();
   if (t < na) {
-    li[t][t] = Scal<T>::one() / g[t][t];
+    li[t * LD + t] = Scal<T>::one() / g[t * LD + t];
     for (int i = t + 1; i < na; ++i) {
       T acc = Scal<T>::zero();
-      for (int k = t; k < i; ++k) acc = Scal<T>::fma(g[i][k], li[k][t], acc);
-      li[i][t] = (Scal<T>::zero() - acc) / g[i][i];
+      for (int k = t; k < i; ++k) acc = Scal<T>::fma(g[i * LD + k], li[k * LD + t], acc);
+      li[i * LD + t] = (Scal<T>::zero() - acc) / g[i * LD + i];
     }
   }
   __syncthreads();
-  if (t < 32) {
-    for (int c = 0; c < 32; ++c) {
-      const bool in = t < na && c < na;
-      if (in) j.Lout[(size_t)t + (size_t)c * j.ldl] = c <= t ? g[t][c] : Scal<T>::zero();
-      j.Linv[(size_t)t + (size_t)c * 32] = in ? li[t][c] : Scal<T>::zero();
-    }
-    // LinvP[:, perm[c]] = Linv[:, c]  (Q_new = Linv * W[perm, :] = LinvP * W)
-    for (int c = 0; c < 32; ++c) j.LinvP[(size_t)t + (size_t)c * 32] = Scal<T>::zero();
+  for (int c = 0; c < W; ++c) {
+    const bool in = t < na && c < na;
+    if (in) j.Lout[(size_t)t + (size_t)c * j.ldl] = c <= t ? g[t * LD + c] : Scal<T>::zero();
+    j.Linv[(size_t)t + (size_t)c * W] = in ? li[t * LD + c] : Scal<T>::zero();
+    j.LinvP[(size_t)t + (size_t)c * W] = Scal<T>::zero();
   }
   __syncthreads();
-  if (t < 32)
-    for (int c = 0; c < na; ++c) j.LinvP[(size_t)t + (size_t)perm[c] * 32] = t < na ? li[t][c] : Scal<T>::zero();
-  if (t < na) j.d[t] = real_of(g[t][t]);
-  __shared__ int oldp[32];
+  // LinvP[:, perm[c]] = Linv[:, c]  (Q_new = Linv * W[perm, :] = LinvP * W)
+  for (int c = 0; c < na; ++c) j.LinvP[(size_t)t + (size_t)perm[c] * W] = t < na ? li[t * LD + c] : Scal<T>::zero();
+  if (t < na) j.d[t] = real_of(g[t * LD + t]);
   if (t < b) oldp[t] = j.p[t];
   __syncthreads();
   if (t < b) {
@@ -631,6 +625,16 @@ __global__ __launch_bounds__(64) void chol_block_kernel(const CholJob<T>* __rest
     *j.nacc = na;
     if (j.first) *j.top = top;
   }
+}
+template <class T>
+static void launch_chol(const CholJob<T>* d, unsigned n, hipStream_t s) {
+  constexpr int lds = (int)(2 * HS_QW * (HS_QW + 1) * sizeof(T) + 2 * HS_QW * sizeof(int));
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KiB of LDS per workgroup needs the opt-in (complex: 131 KiB)
+    (void)hipFuncSetAttribute((const void*)chol_block_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(chol_block_kernel<T>, dim3(n), dim3(64), lds, s, d);
 }
 
 template <class T>
@@ -678,16 +682,16 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     S.Q = tmp.get<T>((size_t)S.ldq * J.q);
     S.Qh = tmp.get<T>((size_t)S.ldqh * J.rmax);
     S.L = tmp.get<T>((size_t)S.ldl * J.rmax);
-    S.W = tmp.get<T>((size_t)32 * J.q);
-    S.Wh = tmp.get<T>((size_t)S.ldqh * 32);
-    S.C1 = tmp.get<T>((size_t)32 * J.rmax);
-    S.C2 = tmp.get<T>((size_t)32 * J.rmax);
-    S.G = tmp.get<T>(1024);
-    S.d = tmp.get<double>((size_t)J.rmax + 32);
+    S.W = tmp.get<T>((size_t)HS_QW * J.q);
+    S.Wh = tmp.get<T>((size_t)S.ldqh * HS_QW);
+    S.C1 = tmp.get<T>((size_t)HS_QW * J.rmax);
+    S.C2 = tmp.get<T>((size_t)HS_QW * J.rmax);
+    S.G = tmp.get<T>(HS_QW * HS_QW);
+    S.d = tmp.get<double>((size_t)J.rmax + HS_QW);
     S.top = tmp.get<double>(4);
-    S.lperm = tmp.get<int>(32);
-    S.nslab = J.rmax / 16 + 8;
-    S.slab = tmp.get<T>((size_t)S.nslab * 2048);
+    S.lperm = tmp.get<int>(HS_QW);
+    S.nslab = J.rmax / (HS_QW / 2) + 8;
+    S.slab = tmp.get<T>((size_t)S.nslab * 2 * HS_QW * HS_QW);
     HSS_HIP(hipMemsetAsync(S.L, 0, sizeof(T) * (size_t)S.ldl * J.rmax, s));
   }
   int* dnacc = tmp.get<int>((size_t)nj);
@@ -704,45 +708,45 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     ++nsteps;
     auto each = [&](auto&& f) {
       for (int a = 0; a < nj; ++a)
-        if (st[a].active) f(a, jobs[a], st[a], std::min(32, jobs[a].rmax - st[a].done));
+        if (st[a].active) f(a, jobs[a], st[a], std::min(HS_QW, jobs[a].rmax - st[a].done));
     };
     // W = M[p[done : done+b], :]
-    each([&](int, QrJob<T>& J, St& S, int b) { rows.push_back(RowJob<T>{J.M, J.ldm, S.W, 32, J.p + S.done, b, J.q, ROW_GATHER}); });
+    each([&](int, QrJob<T>& J, St& S, int b) { rows.push_back(RowJob<T>{J.M, J.ldm, S.W, HS_QW, J.p + S.done, b, J.q, ROW_GATHER}); });
     if (rows.empty()) break;
     run_rows(tmp, rows, s);
     for (int pass = 0; pass < 2; ++pass) {  // classical Gram-Schmidt against the accepted rows, twice
       each([&](int, QrJob<T>& J, St& S, int b) {
         if (S.done == 0) return;
         T* Cx = pass == 0 ? S.C1 : S.C2;
-        HSS_HIP(hipMemsetAsync(Cx, 0, sizeof(T) * (size_t)32 * S.done, s));
-        g.push_back(GemmProb<T>{S.W, S.Qh, Cx, b, S.done, J.q, 32, S.ldqh, 32});
+        HSS_HIP(hipMemsetAsync(Cx, 0, sizeof(T) * (size_t)HS_QW * S.done, s));
+        g.push_back(GemmProb<T>{S.W, S.Qh, Cx, b, S.done, J.q, HS_QW, S.ldqh, HS_QW});
       });
       run_gemms(tmp, g, 0, s);
       each([&](int, QrJob<T>& J, St& S, int b) {
-        if (S.done > 0) g.push_back(GemmProb<T>{pass == 0 ? S.C1 : S.C2, S.Q, S.W, b, J.q, S.done, 32, S.ldq, 32});
+        if (S.done > 0) g.push_back(GemmProb<T>{pass == 0 ? S.C1 : S.C2, S.Q, S.W, b, J.q, S.done, HS_QW, S.ldq, HS_QW});
       });
       run_gemms(tmp, g, 1, s);
     }
     each([&](int, QrJob<T>&, St& S, int b) {  // C1 += C2: the coefficients of the candidates against the accepted rows
-      if (S.done > 0) rows.push_back(RowJob<T>{S.C2, 32, S.C1, 32, nullptr, b, S.done, ROW_SCATTER_ADD});
+      if (S.done > 0) rows.push_back(RowJob<T>{S.C2, HS_QW, S.C1, HS_QW, nullptr, b, S.done, ROW_SCATTER_ADD});
     });
     run_rows(tmp, rows, s);
     // G = W * W^H, pivoted Cholesky of the window
-    each([&](int, QrJob<T>& J, St& S, int b) { subs.push_back(SubJob<T>{S.W, 32, nullptr, nullptr, 0, 0, b, J.q, S.Wh, S.ldqh, 2}); });
+    each([&](int, QrJob<T>& J, St& S, int b) { subs.push_back(SubJob<T>{S.W, HS_QW, nullptr, nullptr, 0, 0, b, J.q, S.Wh, S.ldqh, 2}); });
     run_subs(tmp, subs, s);
     std::vector<CholJob<T>> cj;
     each([&](int a, QrJob<T>& J, St& S, int b) {
-      HSS_HIP(hipMemsetAsync(S.G, 0, sizeof(T) * 1024, s));
-      g.push_back(GemmProb<T>{S.W, S.Wh, S.G, b, b, J.q, 32, S.ldqh, 32});
-      T* slot = S.used < S.nslab ? S.slab + (size_t)(S.used++) * 2048 : tmp.get<T>(2048);
+      HSS_HIP(hipMemsetAsync(S.G, 0, sizeof(T) * HS_QW * HS_QW, s));
+      g.push_back(GemmProb<T>{S.W, S.Wh, S.G, b, b, J.q, HS_QW, S.ldqh, HS_QW});
+      T* slot = S.used < S.nslab ? S.slab + (size_t)(S.used++) * 2 * HS_QW * HS_QW : tmp.get<T>(2 * HS_QW * HS_QW);
       linv[a].push_back(slot);
-      linvp[a].push_back(slot + 1024);
-      cj.push_back(CholJob<T>{S.G, S.L + S.done + (size_t)S.done * S.ldl, S.ldl, slot, slot + 1024, S.d + S.done, S.top, J.p + S.done, S.lperm, S.nacc, atol * J.atol_scale,
+      linvp[a].push_back(slot + HS_QW * HS_QW);
+      cj.push_back(CholJob<T>{S.G, S.L + S.done + (size_t)S.done * S.ldl, S.ldl, slot, slot + HS_QW * HS_QW, S.d + S.done, S.top, J.p + S.done, S.lperm, S.nacc, atol * J.atol_scale,
                               rtol, scale_floor, b, S.done == 0 ? 1 : 0});
     });
     run_gemms(tmp, g, 0, s);
     CholJob<T>* dcj = upload(tmp, cj, s);
-    hipLaunchKernelGGL(chol_block_kernel<T>, dim3((unsigned)cj.size()), dim3(64), 0, s, (const CholJob<T>*)dcj);
+    launch_chol<T>(dcj, (unsigned)cj.size(), s);
     // how many candidates each job accepted
     HSS_HIP(hipMemcpyAsync(hacc.data(), dnacc, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, s));
     HSS_HIP(hipStreamSynchronize(s));
@@ -751,8 +755,8 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       const int na = hacc[a];
       if (na <= 0) return;
       HSS_HIP(hipMemset2DAsync(S.Q + S.done, sizeof(T) * S.ldq, 0, sizeof(T) * na, J.q, s));
-      g.push_back(GemmProb<T>{linvp[a].back(), S.W, S.Q + S.done, na, J.q, b, 32, 32, S.ldq});
-      if (S.done > 0) rows.push_back(RowJob<T>{S.C1, 32, S.L + S.done, S.ldl, S.lperm, na, S.done, ROW_GATHER});
+      g.push_back(GemmProb<T>{linvp[a].back(), S.W, S.Q + S.done, na, J.q, b, HS_QW, HS_QW, S.ldq});
+      if (S.done > 0) rows.push_back(RowJob<T>{S.C1, HS_QW, S.L + S.done, S.ldl, S.lperm, na, S.done, ROW_GATHER});
     });
     run_gemms(tmp, g, 0, s);
     run_rows(tmp, rows, s);
@@ -765,7 +769,7 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     for (int a = 0; a < nj; ++a) {
       St& S = st[a];
       if (!S.active) continue;
-      const int b = std::min(32, jobs[a].rmax - S.done), na = hacc[a];
+      const int b = std::min(HS_QW, jobs[a].rmax - S.done), na = hacc[a];
       if (na > 0) {
         S.blocks.push_back({S.done, na});
         S.done += na;
@@ -804,7 +808,7 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     const int nR = J.m - J.r;
     if (nR <= 0 || J.r <= 0) continue;
     YR[a] = tmp.get<T>((size_t)ev(nR) * J.q);
-    T2[a] = tmp.get<T>((size_t)ev(nR) * 32);
+    T2[a] = tmp.get<T>((size_t)ev(nR) * HS_QW);
     rows.push_back(RowJob<T>{J.M, J.ldm, YR[a], ev(nR), J.p + J.r, nR, J.q, ROW_GATHER});
     HSS_HIP(hipMemsetAsync(J.Tm, 0, sizeof(T) * (size_t)J.ldt * J.r, s));
     g.push_back(GemmProb<T>{YR[a], S.Qh, J.Tm, nR, J.r, J.q, ev(nR), S.ldqh, J.ldt});
@@ -821,8 +825,8 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       if (nR <= 0 || step >= nb_) continue;
       const int bi = nb_ - 1 - step, j0 = S.blocks[bi].first, w = S.blocks[bi].second, j1 = j0 + w;
       if (r > j1) g1.push_back(GemmProb<T>{J.Tm + (size_t)j1 * J.ldt, S.L + j1 + (size_t)j0 * S.ldl, J.Tm + (size_t)j0 * J.ldt, nR, w, r - j1, J.ldt, S.ldl, J.ldt});
-      HSS_HIP(hipMemsetAsync(T2[a], 0, sizeof(T) * (size_t)ev(nR) * 32, s));
-      g2.push_back(GemmProb<T>{J.Tm + (size_t)j0 * J.ldt, linv[a][bi], T2[a], nR, w, w, J.ldt, 32, ev(nR)});
+      HSS_HIP(hipMemsetAsync(T2[a], 0, sizeof(T) * (size_t)ev(nR) * HS_QW, s));
+      g2.push_back(GemmProb<T>{J.Tm + (size_t)j0 * J.ldt, linv[a][bi], T2[a], nR, w, w, J.ldt, HS_QW, ev(nR)});
       back.push_back(SubJob<T>{T2[a], ev(nR), nullptr, nullptr, 0, 0, nR, w, J.Tm + (size_t)j0 * J.ldt, J.ldt, 0});
     }
     run_gemms(tmp, g1, 1, s);
