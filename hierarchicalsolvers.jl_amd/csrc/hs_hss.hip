@@ -409,20 +409,90 @@ void run_subs(Pool& tmp, std::vector<SubJob<T>>& jobs, hipStream_t s) {
     hipLaunchKernelGGL(sub_gather_kernel<T>, dim3((mr + 63) / 64, (mc + 15) / 16, cnt), dim3(64), 0, s, (const SubJob<T>*)(d + b));
   }
 }
+// C (+/-)= sum of `parts` partial products stored one after the other (stride `pstride` elements), column by column
+template <class T>
+struct SplitKJob {
+  const T* part;
+  size_t pstride;
+  int parts, rows, cols, ldp;
+  T* C;
+  int ldc, minus;
+};
+template <class T>
+__global__ __launch_bounds__(64) void splitk_reduce_kernel(const SplitKJob<T>* __restrict__ jobs) {
+  const SplitKJob<T> j = jobs[blockIdx.z];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= j.rows) return;
+  const int c0 = blockIdx.y * 16, c1 = min(c0 + 16, j.cols);
+  for (int c = c0; c < c1; ++c) {
+    T acc = Scal<T>::zero();
+    for (int p = 0; p < j.parts; ++p) acc = acc + j.part[(size_t)p * j.pstride + (size_t)i + (size_t)c * j.ldp];
+    T* dst = j.C + (size_t)i + (size_t)c * j.ldc;
+    *dst = j.minus ? (*dst - acc) : acc;
+  }
+}
+
 // C = A*B (minus = 0; C must not alias) or C -= A*B (minus = 1); problems with an empty dimension are dropped
-// (the callers zero-fill the results of C = A*B beforehand, so K = 0 leaves zeros)
+// (the callers zero-fill the results of C = A*B beforehand, so K = 0 leaves zeros).
+// Skinny products with a long inner dimension (a 64-row window against 8,192 sample columns: ONE 128 x 128 tile walking all of K while
+// the chip idles) are split along K into up to 16 partial products that run as separate tiles, then summed by a small kernel.
 template <class T>
 void run_gemms(Pool& tmp, std::vector<GemmProb<T>>& probs, int minus, hipStream_t s) {
   std::vector<GemmProb<T>> live;
+  std::vector<SplitKJob<T>> red;
   int mM = 0, mN = 0;
+  static const bool splitk = !(getenv("HS_SPLITK") && getenv("HS_SPLITK")[0] == '0');
+  size_t tiles_total = 0;
+  for (auto& p : probs)
+    if (p.M > 0 && p.N > 0 && p.K > 0) tiles_total += (size_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
   for (auto& p : probs)
     if (p.M > 0 && p.N > 0 && p.K > 0) {
+      const size_t tiles = (size_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+      if (splitk && tiles_total < 256 && p.K >= 2048) {
+        int parts = (int)std::min<size_t>(16, std::max<size_t>(2, 512 / std::max<size_t>(tiles_total, 1)));
+        parts = std::min(parts, p.K / 512);
+        if (parts >= 2) {
+          const int ldp = ev(p.M);
+          const size_t pstride = (size_t)ldp * p.N;
+          T* part = tmp.get<T>(pstride * parts);
+          const int kc = ((p.K + parts - 1) / parts + 15) / 16 * 16;
+          int used = 0;
+          for (int q = 0; q * kc < p.K; ++q, ++used) {
+            const int k0 = q * kc, kw = std::min(kc, p.K - k0);
+            live.push_back(GemmProb<T>{p.A + (size_t)k0 * p.lda, p.B + k0, part + (size_t)q * pstride, p.M, p.N, kw, p.lda, p.ldb, ldp});
+          }
+          red.push_back(SplitKJob<T>{part, pstride, used, p.M, p.N, ldp, p.C, p.ldc, minus});
+          mM = std::max(mM, p.M);
+          mN = std::max(mN, p.N);
+          (void)tiles;
+          continue;
+        }
+      }
       live.push_back(p);
       mM = std::max(mM, p.M);
       mN = std::max(mN, p.N);
     }
   probs.clear();
   if (live.empty()) return;
+  if (!red.empty()) {
+    // the partial products are plain C = A*B; the direct problems keep the caller's mode: two launches when both kinds are present
+    std::vector<GemmProb<T>> direct, parts;
+    for (auto& p : live) {
+      bool is_part = false;
+      for (auto& r : red)
+        if (p.C >= r.part && p.C < r.part + r.pstride * r.parts) is_part = true;
+      (is_part ? parts : direct).push_back(p);
+    }
+    GemmProb<T>* dp = upload(tmp, parts, s);
+    for (size_t b = 0; b < parts.size(); b += 32768) launch_gemm_probs<T>(dp + b, (int)std::min<size_t>(32768, parts.size() - b), mM, mN, 0, s);
+    if (!direct.empty()) {
+      GemmProb<T>* dd = upload(tmp, direct, s);
+      for (size_t b = 0; b < direct.size(); b += 32768) launch_gemm_probs<T>(dd + b, (int)std::min<size_t>(32768, direct.size() - b), mM, mN, minus, s);
+    }
+    SplitKJob<T>* dr = upload(tmp, red, s);
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((mM + 63) / 64, (mN + 15) / 16, (unsigned)red.size()), dim3(64), 0, s, (const SplitKJob<T>*)dr);
+    return;
+  }
   GemmProb<T>* d = upload(tmp, live, s);
   for (size_t b = 0; b < live.size(); b += 32768) {
     const int cnt = (int)std::min<size_t>(32768, live.size() - b);
