@@ -464,7 +464,10 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr, const SplitTr
 
 static void dmalloc(void** p, size_t bytes, const char* what);
 template <class T>
-static void mf_compress_schur_dense(hs_handle* h, int id, const T* SB, int lds, const T* C_, int ldc, const T* M, int ldm, const T* Z, int ldz, int r1, int r2);
+static void mf_compress_schur_dense(hs_handle* h, int id, const T* SB, int lds, const T* C_, int ldc, const T* M, int ldm, const T* Z, int ldz, int r1, int r2,
+                                    hipStream_t stream);
+template <class F>
+static void mf_parallel(hs_handle* h, int count, F&& body);
 #include "hs_compress.h"
 #include "hs_hssfront.h"
 #define MfCoupling NodeH::Coupling
@@ -959,9 +962,15 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     }
     if (L.nplain > 0) factor_compressed_level<T>(h, L.mine.data() + L.ndense, L.nplain, dn + L.ndense, (const SolveNode<T>*)h->d_solve + L.desc_off + L.ndense);  // hs_compress.h
     if (nb_ > L.ndense + L.nplain) factor_hss_fronts<T>(h, L.mine.data() + L.ndense + L.nplain, nb_ - L.ndense - L.nplain, dn + L.ndense + L.nplain);  // hs_hssfront.h
-    for (int k = 0; k < L.ndense; ++k) {  // F2: a flagged front eliminated densely (a leaf) still hands its S on as an HSS matrix (factorization.jl:45-59)
-      const NodeH& x = h->nodes[L.mine[k]];
-      if (x.s_hss) mf_compress_schur_dense<T>(h, L.mine[k], x.ext_sb ? (const T*)x.ext_sb : dsb + x.off_SB, x.lds, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0);
+    {  // F2: a flagged front eliminated densely (a leaf) still hands its S on as an HSS matrix (factorization.jl:45-59)
+      std::vector<int> todo;
+      for (int k = 0; k < L.ndense; ++k)
+        if (h->nodes[L.mine[k]].s_hss) todo.push_back(L.mine[k]);
+      if (!todo.empty())
+        mf_parallel(h, (int)todo.size(), [&](int k, hipStream_t st) {
+          const NodeH& x = h->nodes[todo[k]];
+          mf_compress_schur_dense<T>(h, todo[k], x.ext_sb ? (const T*)x.ext_sb : dsb + x.off_SB, x.lds, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, st);
+        });
     }
     if (L.nmf > 0) factor_mf_fronts<T>(h, L.mine.data() + nb_, L.nmf);  // hs_mffront.h
     static const bool lvl_env = getenv("HS_VERBOSE_LEVELS") != nullptr;

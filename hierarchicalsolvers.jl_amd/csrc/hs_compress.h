@@ -216,16 +216,22 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
           launch_gemm_probs<T>(dgp + 2 * count, count, maxnb, maxnb, 1, s);
         }
         lap("E: Schur update");
-        for (int i = 0; i < count; ++i) {  // the transition of the matrix-free branch: `randcompress_adaptive` on the Schur operator (factorization.jl:108-110)
-          if (!h->nodes[ids[i]].s_hss || !W2[i]) continue;
-          const int ldw2 = (LL[i]->r + 1) / 2 * 2;
-          mf_compress_schur_dense<T>(h, ids[i], hd[i].SB, hd[i].lds, LL[i]->Cd, LL[i]->ldc, W2[i], ldw2, RR[i]->Z, RR[i]->ldz, LL[i]->r, RR[i]->r);
+        {  // the transition of the matrix-free branch: `randcompress_adaptive` on the Schur operator (factorization.jl:108-110)
+          std::vector<int> todo;
+          for (int i = 0; i < count; ++i)
+            if (h->nodes[ids[i]].s_hss && W2[i]) todo.push_back(i);
+          if (!todo.empty())
+            mf_parallel(h, (int)todo.size(), [&](int t, hipStream_t st) {
+              const int i = todo[t];
+              const int ldw2 = (LL[i]->r + 1) / 2 * 2;
+              mf_compress_schur_dense<T>(h, ids[i], hd[i].SB, hd[i].lds, LL[i]->Cd, LL[i]->ldc, W2[i], ldw2, RR[i]->Z, RR[i]->ldz, LL[i]->r, RR[i]->r, st);
+            });
         }
         lap("S: HSS compression of the Schur operator");
       }
     }
     for (int i = 0; i < count; ++i)  // fronts without a low-rank update (a rank came out 0): S = Abb as assembled
-      if (h->nodes[ids[i]].s_hss && !h->nodes[ids[i]].S_hss) mf_compress_schur_dense<T>(h, ids[i], hd[i].SB, hd[i].lds, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0);
+      if (h->nodes[ids[i]].s_hss && !h->nodes[ids[i]].S_hss) mf_compress_schur_dense<T>(h, ids[i], hd[i].SB, hd[i].lds, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, s);
     // F. Z_L' = Z_L * U^-1 (Z_L is consumed)
     {
       std::vector<RtrsmJob<T>> rj(count);

@@ -21,6 +21,9 @@
 // as `Abi_lr * (D^-1 x)` in `ldiv!` (one HSS solve serves `_dsolve!` and `_lsolve!`), so no transposed HSS solve is needed.
 // PARITY UNPINNED (HssMatrices.jl / LowRankApprox.jl are not part of the reference tree); checked against a CPU restatement of the same data flow (tests/test_mf_gpu.py).
 #pragma once
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include "../../include/hs_hss.h"
 #include "hs_lowrank.h"
 
@@ -144,22 +147,84 @@ static void mf_check(int st) {
   if (st != 0) throw HsError{st};
 }
 
+// The compressions of the fronts of one level are independent chains of small dependent launches (tree levels x windows of rows): run
+// alone, each leaves most of the chip idle.  Up to HS_MF_THREADS (default 4) of them run concurrently, one host thread and one HIP stream
+// each (the HSS module is synchronous per call; its block caches are mutex-guarded, its error state thread-local).  body(i, stream) may
+// throw HsError / int; the first failure is re-raised on the calling thread with its message.
+static std::mutex g_mf_mu;  // guards hs_handle::maxrank and verbose output ordering
+template <class F>
+static void mf_parallel(hs_handle* h, int count, F&& body) {
+  static const int nth_env = getenv("HS_MF_THREADS") ? atoi(getenv("HS_MF_THREADS")) : 4;
+  const int nth = std::max(1, std::min(count, nth_env));
+  HS_HIP(hipStreamSynchronize(h->stream));  // everything the fronts read has been produced
+  if (nth == 1) {
+    for (int i = 0; i < count; ++i) body(i, h->stream);
+    return;
+  }
+  int dev = 0;
+  HS_HIP(hipGetDevice(&dev));
+  std::atomic<int> next{0};
+  std::vector<int> codes(nth, 0);
+  std::vector<std::string> msgs(nth);
+  std::vector<long long> infos(nth, 0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t)
+    th.emplace_back([&, t]() {
+      hipStream_t st = nullptr;
+      if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&st) != hipSuccess) {
+        codes[t] = HS_ERR_DEVICE;
+        msgs[t] = "hipSetDevice / hipStreamCreate failed in a worker of the matrix-free level";
+        return;
+      }
+      try {
+        for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) {
+          body(i, st);
+          if (hipStreamSynchronize(st) != hipSuccess) throw HsError{HS_ERR_DEVICE};
+        }
+      } catch (const HsError& e) {
+        codes[t] = e.code;
+      } catch (int c) {
+        codes[t] = c;
+      } catch (const std::bad_alloc&) {
+        codes[t] = HS_ERR_NOMEM;
+      }
+      if (codes[t] != 0) {
+        msgs[t] = hs_last_error();
+        infos[t] = hs_last_error_info();
+        next.store(count);  // the others stop at their next front
+      }
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    });
+  for (auto& t : th) t.join();
+  for (int t = 0; t < nth; ++t)
+    if (codes[t] != 0) {
+      hs_set_error(codes[t], infos[t], "%s", msgs[t].c_str());
+      throw HsError{codes[t]};
+    }
+}
+static void mf_maxrank(hs_handle* h, int64_t r) {
+  std::lock_guard<std::mutex> lk(g_mf_mu);
+  h->maxrank = std::max<int64_t>(h->maxrank, r);
+}
+
 // S of a front that was eliminated on its dense front (a transition branch or a flagged leaf) leaves as an HSS matrix:
 // H ~= (SB - C*M*Z)[perm, perm], perm = [int_loc; bnd_loc], first split at |int_loc| (factorization.jl:56-57,108-110)
 template <class T>
-static void mf_compress_schur_dense(hs_handle* h, int id, const T* SB, int lds, const T* C_, int ldc, const T* M, int ldm, const T* Z, int ldz, int r1, int r2) {
+static void mf_compress_schur_dense(hs_handle* h, int id, const T* SB, int lds, const T* C_, int ldc, const T* M, int ldm, const T* Z, int ldz, int r1, int r2,
+                                    hipStream_t stream) {
   NodeH& x = h->nodes[id];
   const int64_t fs = (x.n1p > 0 && x.n1p < x.nb) ? x.n1p : 0;
   hs_hss_options o = mf_options(h, id, 1.0, fs, x.last_ks, x.nb);
   hs_hss* H = nullptr;
   const int st = h->is_complex ? hs_hss_compress_lru_z(x.nb, (const double*)SB, lds, (const double*)C_, ldc, (const double*)M, ldm, (const double*)Z, ldz, r1, r2, 1,
-                                                       x.sperm.data(), &o, h->stream, &H)
+                                                       x.sperm.data(), &o, stream, &H)
                                : hs_hss_compress_lru_d(x.nb, (const double*)SB, lds, (const double*)C_, ldc, (const double*)M, ldm, (const double*)Z, ldz, r1, r2, 1,
-                                                       x.sperm.data(), &o, h->stream, &H);
+                                                       x.sperm.data(), &o, stream, &H);
   mf_check(st);
   x.S_hss = H;
   x.last_ks = (int)hs_hss_samples(H);
-  h->maxrank = std::max<int64_t>(h->maxrank, hs_hss_rank(H));
+  mf_maxrank(h, hs_hss_rank(H));
   if (h->opts.verbose) fprintf(stderr, "[hs] node %d (level %d, nb=%d): hssrank(S)=%lld (%lld samples)\n", id, x.level, x.nb, (long long)hs_hss_rank(H), (long long)hs_hss_samples(H));
 }
 
@@ -175,10 +240,11 @@ struct MfChild {
     if (a22) hs_hss_free(a22);
     a11 = a22 = nullptr;
   }
-  void open(hs_hss* S_, int n1_, int nb) {
+  void open(hs_hss* S_, int n1_, int nb, hipStream_t s) {
     S = S_;
     n1 = n1_;
     n2 = nb - n1_;
+    mf_check(hs_hss_set_stream(S, (void*)s));  // the stream it was compressed on may belong to a worker that is gone; views inherit this one
     if (n1 > 0 && n2 > 0) {
       mf_check(hs_hss_child(S, 0, &a11));
       mf_check(hs_hss_child(S, 1, &a22));
@@ -238,23 +304,22 @@ static int mf_factor_coupling(const MfCoupling& X, int c_off, std::vector<HsFill
 }
 
 template <class T>
-static void mf_fill(hs_handle* h, const std::vector<HsFillEntry>& f, T* out, int ld, MfBuf<T>& buf) {
+static void mf_fill(hs_handle* h, const std::vector<HsFillEntry>& f, T* out, int ld, MfBuf<T>& buf, hipStream_t s) {
   if (f.empty()) return;
   HsFillEntry* d = (HsFillEntry*)buf.get((f.size() * sizeof(HsFillEntry) + sizeof(T) - 1) / sizeof(T), "coupling entries");
-  HS_HIP(hipMemcpyAsync(d, f.data(), f.size() * sizeof(HsFillEntry), hipMemcpyHostToDevice, h->stream));
-  HS_HIP(hipStreamSynchronize(h->stream));
-  launch_fill_entries<T>(d, (int)f.size(), (const T*)h->d_nz, out, ld, h->stream);
+  HS_HIP(hipMemcpyAsync(d, f.data(), f.size() * sizeof(HsFillEntry), hipMemcpyHostToDevice, s));
+  HS_HIP(hipStreamSynchronize(s));
+  launch_fill_entries<T>(d, (int)f.size(), (const T*)h->d_nz, out, ld, s);
 }
 
 // ---- numeric: the matrix-free fronts of one level, one at a time (they are the few large fronts at the top of the tree) --------------
 template <class T>
 static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
-  hipStream_t s = h->stream;
   static const bool vt = getenv("HS_VERBOSE_COMPRESS") != nullptr;
   const bool say = h->opts.verbose || vt;
   hs_sparse_dev As{h->n, h->d_colptr, h->d_rowval, h->d_nz, h->d_rowptr, h->d_colind, h->d_nzr};
   const double dsc = std::pow(10.0, -(double)(h->opts.hss_dexp == 0 ? 2 : h->opts.hss_dexp - 1));  // hs_options.hss_dexp
-  for (int k = 0; k < count; ++k) {
+  mf_parallel(h, count, [&](int k, hipStream_t s) {
     const int id = ids[k];
     NodeH& x = h->nodes[id];
     NodeH &c1 = h->nodes[x.left], &c2 = h->nodes[x.right];
@@ -268,8 +333,8 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
       t0 = now;
     };
     MfChild ch1, ch2;
-    ch1.open((hs_hss*)c1.S_hss, c1.n1p, c1.nb);
-    ch2.open((hs_hss*)c2.S_hss, c2.n1p, c2.nb);
+    ch1.open((hs_hss*)c1.S_hss, c1.n1p, c1.nb, s);
+    ch2.open((hs_hss*)c2.S_hss, c2.n1p, c2.nb, s);
     if (ch1.n1 != x.ni1 || ch1.n1 + ch2.n1 != x.ni || ch1.n2 != x.nb1 || ch1.n2 + ch2.n2 != x.nb)
       HS_FAIL(HS_ERR_DIMENSION, id, "internal: children of node %d contribute (%d+%d, %d+%d) DOFs, expected (%d, %d)", id, ch1.n1, ch2.n1, ch1.n2, ch2.n2, x.ni, x.nb);
     std::vector<int64_t> gid((size_t)x.m);
@@ -292,7 +357,7 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
       }
       lap("D: HSS elimination");
       x.last_k = (int)hs_hss_samples(D);
-      h->maxrank = std::max<int64_t>(h->maxrank, hs_hss_rank(D));
+      mf_maxrank(h, hs_hss_rank(D));
       if (say) fprintf(stderr, "[hs] node %d (level %d, ni=%d, nb=%d): hssrank(D)=%lld (%lld samples), matrix-free\n", id, x.level, x.ni, x.nb, (long long)hs_hss_rank(D), (long long)hs_hss_samples(D));
       if (!x.ht) dmalloc(&x.ht, ((size_t)x.ni + 32) * sizeof(T), "HSS solve vector");
     }
@@ -307,7 +372,7 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
     };
     if (x.nb == 0) {
       release_children();
-      continue;
+      return;
     }
     // ---- Aib = C_R*Z_R and Abi = C_L*Z_L from the children's generators + the sparse couplings (nothing is recompressed) -------------------
     std::vector<HsFillEntry> fcR, fzR, fcL, fzL;
@@ -343,13 +408,13 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
     // Abi: rows bnd, columns int;  block (1,1) = A21 of S1, block (2,2) = A21 of S2
     offd(ch1, 1, lrL->Cd, lrL->ldc, lrL->Z, lrL->ldz);
     offd(ch2, 1, lrL->Cd + ch1.n2 + (size_t)oL2 * lrL->ldc, lrL->ldc, lrL->Z + oL2 + (size_t)ch1.n1 * lrL->ldz, lrL->ldz);
-    mf_fill<T>(h, fcR, lrR->Cd, lrR->ldc, buf);
-    mf_fill<T>(h, fzR, lrR->Z, lrR->ldz, buf);
-    mf_fill<T>(h, fcL, lrL->Cd, lrL->ldc, buf);
-    mf_fill<T>(h, fzL, lrL->Z, lrL->ldz, buf);
+    mf_fill<T>(h, fcR, lrR->Cd, lrR->ldc, buf, s);
+    mf_fill<T>(h, fzR, lrR->Z, lrR->ldz, buf, s);
+    mf_fill<T>(h, fcL, lrL->Cd, lrL->ldc, buf, s);
+    mf_fill<T>(h, fzL, lrL->Z, lrL->ldz, buf, s);
     x.last_rL = rL;
     x.last_rR = rR;
-    h->maxrank = std::max<int64_t>(h->maxrank, std::max(rL, rR));
+    mf_maxrank(h, std::max(rL, rR));
     if (say)
       fprintf(stderr, "[hs] node %d (level %d, ni=%d, nb=%d): rank(L)=%d (%d+%d from the children, %d sparse) rank(R)=%d (%d+%d, %d sparse)\n", id, x.level, x.ni,
               x.nb, rL, ch1.r21, ch2.r21, rL - oLx, rR, ch1.r12, ch2.r12, rR - oRx);
@@ -388,7 +453,7 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
                                                          upd ? rR : 0, x.sperm.data(), &o, s, &Sh));
       x.S_hss = Sh;
       x.last_ks = (int)hs_hss_samples(Sh);
-      h->maxrank = std::max<int64_t>(h->maxrank, hs_hss_rank(Sh));
+      mf_maxrank(h, hs_hss_rank(Sh));
       if (say) fprintf(stderr, "[hs] node %d (level %d, nb=%d): hssrank(S)=%lld (%lld samples), matrix-free\n", id, x.level, x.nb, (long long)hs_hss_rank(Sh), (long long)hs_hss_samples(Sh));
       lap("S: compress(Abb - Abi R) matrix-free");
     } else {
@@ -416,5 +481,5 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
     }
     HS_HIP(hipStreamSynchronize(s));
     release_children();
-  }
+  });
 }
