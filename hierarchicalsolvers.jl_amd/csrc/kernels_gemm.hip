@@ -571,6 +571,59 @@ __global__ __launch_bounds__(256) void mfma_f64_rate_kernel(double* out, int ite
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The same loop on RANDOM operands that change every iteration: under such data the chip holds its clock below the 2.4 GHz the datasheet
+// peak assumes (MI355X_MICROARCH.md, "DVFS give-back"), so this is the FP64 MFMA rate a real GEMM can approach.
+__global__ __launch_bounds__(256) void mfma_f64_rate_random_kernel(double* out, int iters, unsigned long long seed) {
+  double4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  unsigned long long x = seed + (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+  auto next = [&]() {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    return (double)(long long)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  };
+  double a[4], b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a[q] = next(); b[q] = next(); }
+  for (int it = 0; it < iters; it += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(u + i) & 3], b[(u + 2 * i + (i >> 1)) & 3], acc[i], 0, 0, 0);
+    if ((it & 1023) == 1020) {  // refresh the operands now and then (outside the hot issue pattern)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a[q] = next(); b[q] = next(); }
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+extern "C" double hsk_mfma_f64_peak_random(int waves_per_simd, int iters) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1.0;
+  const int blocks = prop.multiProcessorCount * waves_per_simd;
+  double* out = nullptr;
+  if (hipMalloc(&out, sizeof(double) * blocks * 256) != hipSuccess) return -1.0;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(mfma_f64_rate_random_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 12345ull);  // warm-up: the clock settles under load
+  (void)hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(mfma_f64_rate_random_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 67890ull);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+  return flops / (ms * 1e-3) / 1e12;
+}
+
 // returns measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 (every CU, waves_per_simd waves per SIMD)
 extern "C" double hsk_mfma_f64_peak(int waves_per_simd, int iters) {
   int dev = 0;

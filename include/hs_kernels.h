@@ -47,6 +47,8 @@ int hsk_bisect_perm(int64_t n, const int64_t* colptr, const int64_t* rowval, int
 
 /* Measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on every CU (roofline denominator). */
 double hsk_mfma_f64_peak(int waves_per_simd, int iters);
+/* The same issue loop on random operands that change while it runs: the rate at the clock the chip holds under such data (DVFS). */
+double hsk_mfma_f64_peak_random(int waves_per_simd, int iters);
 
 #ifdef __cplusplus
 }
