@@ -38,6 +38,35 @@ __host__ __device__ inline cplx operator/(cplx a, cplx b) {
   }
 }
 
+// Global-address-space accessors.  Matrix pointers reach the kernels through descriptors read from memory (NodeDesc,
+// GemmProb, ...), so the compiler only knows them as generic pointers and emits flat_load / flat_store.  A flat access
+// counts on lgkmcnt as well as vmcnt: every `s_waitcnt lgkmcnt(0)` in front of an LDS operand read then also waits for
+// the global prefetch issued just before it, which serialises the software pipeline of the tile kernels.  gld/gst cast
+// to address space 1, the accesses become global_load / global_store (vmcnt only).
+#define HS_AS_GLOBAL __attribute__((address_space(1)))
+typedef double hs_d2u __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte access, 8-byte aligned
+template <class T>
+__device__ __forceinline__ T gld(const T* p) {
+  return *(const T HS_AS_GLOBAL*)p;
+}
+template <>
+__device__ __forceinline__ cplx gld<cplx>(const cplx* p) {
+  hs_d2u v = *(const hs_d2u HS_AS_GLOBAL*)p;
+  return {v.x, v.y};
+}
+template <class T>
+__device__ __forceinline__ void gst(T* p, T v) {
+  *(T HS_AS_GLOBAL*)p = v;
+}
+template <>
+__device__ __forceinline__ void gst<cplx>(cplx* p, cplx v) {
+  hs_d2u w = {v.re, v.im};
+  *(hs_d2u HS_AS_GLOBAL*)p = w;
+}
+__device__ __forceinline__ hs_d2u gld2(const double* p) { return *(const hs_d2u HS_AS_GLOBAL*)p; }
+__device__ __forceinline__ hs_d2u gld2(const cplx* p) { return *(const hs_d2u HS_AS_GLOBAL*)p; }
+__device__ __forceinline__ void gst2(cplx* p, hs_d2u v) { *(hs_d2u HS_AS_GLOBAL*)p = v; }
+
 template <class T>
 struct Scal;
 template <>

@@ -26,7 +26,7 @@
 #include "hs_common.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte load, 8-byte aligned
+typedef hs_d2u double2_u;
 
 #define BM 128
 #define BK 16
@@ -142,16 +142,16 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
     if (interior && k0 + BK <= K) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        ra[i] = *reinterpret_cast<const double2_u*>(A + (size_t)(m0 + 2 * a_pair) + (size_t)(k0 + a_k + 4 * i) * p.lda);
+        ra[i] = gld2(A + (size_t)(m0 + 2 * a_pair) + (size_t)(k0 + a_k + 4 * i) * p.lda);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        rb[i] = *reinterpret_cast<const double2_u*>(B + (size_t)(k0 + 2 * b_kp) + (size_t)(n0 + b_n + 32 * i) * p.ldb);
+        rb[i] = gld2(B + (size_t)(k0 + 2 * b_kp) + (size_t)(n0 + b_n + 32 * i) * p.ldb);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int kk = k0 + a_k + 4 * i, mm = m0 + 2 * a_pair;
         const double* col = A + (size_t)min(kk, K - 1) * p.lda;
-        double x = col[min(mm, M - 1)], y = col[min(mm + 1, M - 1)];
+        double x = gld(col + min(mm, M - 1)), y = gld(col + min(mm + 1, M - 1));
         const bool kok = kk < K;
         ra[i].x = (kok && mm < M) ? x : 0.0;
         ra[i].y = (kok && mm + 1 < M) ? y : 0.0;
@@ -160,7 +160,7 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
       for (int i = 0; i < 4; ++i) {
         const int nn = n0 + b_n + 32 * i, kk = k0 + 2 * b_kp;
         const double* col = B + (size_t)min(nn, N - 1) * p.ldb;
-        double x = col[min(kk, K - 1)], y = col[min(kk + 1, K - 1)];
+        double x = gld(col + min(kk, K - 1)), y = gld(col + min(kk + 1, K - 1));
         const bool nok = nn < N;
         rb[i].x = (nok && kk < K) ? x : 0.0;
         rb[i].y = (nok && kk + 1 < K) ? y : 0.0;
@@ -206,6 +206,34 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
     if (more) load_tile(k0 + BK);
     const double* a_rd = smem + cur * STAGE + a_off;
     const double* b_rd = smem + cur * STAGE + b_off;
+#ifndef HS_GEMM_CHAINED
+    // Interleaved issue: with VGPR accumulators (-amdgpu-mfma-vgpr-form) independent v_mfma_f64_16x16x4_f64 issue every 64 cycles, while a
+    // MFMA that reads the accumulator the previous one wrote waits ~10 cycles for it (74 cycles/MFMA in chains of 4, tools/mfma_f64_probe.hip)
+    // -- and the partner wave of the SIMD cannot use a bubble shorter than one MFMA.  So each k-step of the tile visits all 16 accumulators.
+    {
+      double af[2][4], bf[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[0][j] = b_rd[(j * 16) * LDB_S];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[0][i] = a_rd[i * 16];
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        const int c = ks & 1, n = c ^ 1;
+        if (ks + 1 < BK / 4) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[n][j] = b_rd[(j * 16) * LDB_S + (ks + 1) * 4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[n][i] = a_rd[((ks + 1) * 4) * LDS_LD + i * 16];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            // transposed issue: MFMA-A <- B data (n on the register/row axis), MFMA-B <- A data (m on lane&15)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[c][j], af[c][i], acc[i][j], 0, 0, 0);
+      }
+    }
+#else
     // Chained issue: v_mfma_f64_16x16x4_f64 pays ~40 extra cycles whenever consecutive MFMAs use a
     // different accumulator (C read + D write through the register file); back-to-back MFMAs on the
     // SAME accumulator forward it inside the pipe (measured: 105 -> 74 cycles/MFMA at chain 4,
@@ -240,6 +268,7 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
         }
       }
     }
+#endif
     if (more) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
@@ -259,14 +288,14 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int nn = n0 + wn * 64 + j * 16 + l4 + 4 * r;
-        cv[j][r] = (minus && rok && nn < N) ? C[(size_t)mm + (size_t)nn * p.ldc] : 0.0;
+        cv[j][r] = (minus && rok && nn < N) ? gld(C + (size_t)mm + (size_t)nn * p.ldc) : 0.0;
       }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int nn = n0 + wn * 64 + j * 16 + l4 + 4 * r;
-        if (rok && nn < N) C[(size_t)mm + (size_t)nn * p.ldc] = minus ? (cv[j][r] - acc[i][j][r]) : acc[i][j][r];
+        if (rok && nn < N) gst(C + (size_t)mm + (size_t)nn * p.ldc, minus ? (cv[j][r] - acc[i][j][r]) : acc[i][j][r]);
       }
   }
 }
@@ -300,7 +329,7 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int kk = k0 + a_k + 2 * i, mm = m0 + a_m;
-      double2_u v = *reinterpret_cast<const double2_u*>(A + (size_t)min(mm, M - 1) + (size_t)min(kk, K - 1) * p.lda);
+      double2_u v = gld2(A + (size_t)min(mm, M - 1) + (size_t)min(kk, K - 1) * p.lda);
       const bool ok = kk < K && mm < M;
       ra[i].x = ok ? v.x : 0.0;
       ra[i].y = ok ? v.y : 0.0;
@@ -308,7 +337,7 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kk = k0 + b_k, nn = n0 + b_n + 16 * i;
-      double2_u v = *reinterpret_cast<const double2_u*>(B + (size_t)min(kk, K - 1) + (size_t)min(nn, N - 1) * p.ldb);
+      double2_u v = gld2(B + (size_t)min(kk, K - 1) + (size_t)min(nn, N - 1) * p.ldb);
       const bool ok = kk < K && nn < N;
       rb[i].x = ok ? v.x : 0.0;
       rb[i].y = ok ? v.y : 0.0;
@@ -399,7 +428,7 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
       for (int r = 0; r < 4; ++r) {
         const int nn = n0 + wn * 32 + j * 16 + l4 + 4 * r;
         double2_u o = {0.0, 0.0};
-        if (minus && rok && nn < N) o = *reinterpret_cast<const double2_u*>(C + (size_t)mm + (size_t)nn * p.ldc);
+        if (minus && rok && nn < N) o = gld2(C + (size_t)mm + (size_t)nn * p.ldc);
         cv[j][r] = o;
       }
 #pragma unroll
@@ -413,7 +442,7 @@ __device__ inline void gemm_tile_z(const GemmProb<cplx>& p, int tile_m, int tile
             v.x = cv[j][r].x - v.x;
             v.y = cv[j][r].y - v.y;
           }
-          *reinterpret_cast<double2_u*>(C + (size_t)mm + (size_t)nn * p.ldc) = v;
+          gst2(C + (size_t)mm + (size_t)nn * p.ldc, v);
         }
       }
   }

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void fwd_gather_kernel(const SolveNode<T>* __r
   const SolveNode<T> nd = nodes[blockIdx.y];
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nd.ni) return;
-  w[nd.woff + i] = b[nd.fidx[nd.rperm[i]]];
+  w[nd.woff + i] = b[gld(nd.fidx + gld(nd.rperm + i))];
 }
 
 // forward step on column block `blk`: y_blk = invL * w_blk ; rows below -= L[:, blk] * y_blk
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const SolveNode<T>* __res
   if (t < HS_PB) {
     const T* il = nd.invL + (size_t)blk * HS_PB * HS_PB;
     T s = Scal<T>::zero();
-    for (int j = 0; j <= t; ++j) s = Scal<T>::fma(il[t + j * HS_PB], s_raw[j], s);
+    for (int j = 0; j <= t; ++j) s = Scal<T>::fma(gld(il + t + j * HS_PB), s_raw[j], s);
     s_y[t] = s;
     if (blockIdx.x == 0 && t < wl) y[nd.woff + c0 + t] = s;
   }
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const SolveNode<T>* __res
   if (r >= nd.mrows) return;
   const T* a = nd.LF + (size_t)r + (size_t)c0 * nd.ldl;
   T acc = Scal<T>::zero();
-#pragma unroll 8
-  for (int j = 0; j < wl; ++j) acc = Scal<T>::fma(a[(size_t)j * nd.ldl], s_y[j], acc);
+#pragma unroll 32
+  for (int j = 0; j < wl; ++j) acc = Scal<T>::fma(gld(a + (size_t)j * nd.ldl), s_y[j], acc);
   if (r < nd.ni) {
     w[nd.woff + r] = w[nd.woff + r] - acc;
   } else {
-    int g = nd.fidx[r];
+    int g = gld(nd.fidx + r);
     b[g] = b[g] - acc;
   }
 }
@@ -72,14 +72,14 @@ __global__ __launch_bounds__(256) void int_update_partial_kernel(const SolveNode
   if ((int)blockIdx.x * 256 >= nd.ni) return;
   const int j1 = min(nd.nb, j0 + UPD_CS);
   __shared__ T s_b[UPD_CS];
-  for (int j = threadIdx.x; j < j1 - j0; j += 256) s_b[j] = b[nd.fidx[nd.ni + j0 + j]];
+  for (int j = threadIdx.x; j < j1 - j0; j += 256) s_b[j] = b[gld(nd.fidx + nd.ni + j0 + j)];
   __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nd.ni) return;
   const T* u = nd.UR + (size_t)i + (size_t)j0 * nd.ldu;
   T acc = Scal<T>::zero();
-#pragma unroll 8
-  for (int j = 0; j < j1 - j0; ++j) acc = Scal<T>::fma(u[(size_t)j * nd.ldu], s_b[j], acc);
+#pragma unroll 32
+  for (int j = 0; j < j1 - j0; ++j) acc = Scal<T>::fma(gld(u + (size_t)j * nd.ldu), s_b[j], acc);
   part[nd.poff + (long long)blockIdx.y * nd.ni + i] = acc;
 }
 template <class T>
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const SolveNode<T>* __res
   if (t < HS_PB) {
     const T* iu = nd.invU + (size_t)blk * HS_PB * HS_PB;
     T s = Scal<T>::zero();
-    for (int j = t; j < HS_PB; ++j) s = Scal<T>::fma(iu[t + j * HS_PB], s_raw[j], s);
+    for (int j = t; j < HS_PB; ++j) s = Scal<T>::fma(gld(iu + t + j * HS_PB), s_raw[j], s);
     s_x[t] = s;
     if (blockIdx.x == 0 && t < wl) x[nd.woff + c0 + t] = s;
   }
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const SolveNode<T>* __res
   if (r >= c0) return;
   const T* a = nd.LF + (size_t)r + (size_t)c0 * nd.ldl;
   T acc = Scal<T>::zero();
-#pragma unroll 8
-  for (int j = 0; j < wl; ++j) acc = Scal<T>::fma(a[(size_t)j * nd.ldl], s_x[j], acc);
+#pragma unroll 32
+  for (int j = 0; j < wl; ++j) acc = Scal<T>::fma(gld(a + (size_t)j * nd.ldl), s_x[j], acc);
   w[nd.woff + r] = w[nd.woff + r] - acc;
 }
 
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void bwd_scatter_kernel(const SolveNode<T>* __
   const SolveNode<T> nd = nodes[blockIdx.y];
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nd.ni) return;
-  b[nd.fidx[i]] = x[nd.woff + i];
+  b[gld(nd.fidx + i)] = x[nd.woff + i];
 }
 
 // ---- low-rank Gauss transforms (compressed fronts) ---------------------------------------------------

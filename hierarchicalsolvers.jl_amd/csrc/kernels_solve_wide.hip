@@ -87,78 +87,162 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
     }
 }
 
+// The sweeps below are chains of dependent launches (ni / 256 per front and sweep), so what matters for the large fronts is the latency of
+// one step, i.e. the number of dependent memory round trips in it (measured: 22 us per step whatever the size of the front).
+//  * A workgroup is 1024 threads = 256 rows x 4 column groups of 64: every thread has at most 64 loads, issued 32 at a time, and the four
+//    partial sums of a row meet in LDS (256 threads with one row each, loads dependent by eight: 74 us per forward step at Poisson 128^3).
+//  * The product with the stored inverse of the diagonal block is taken OFF the chain of all workgroups but one: the workgroup whose rows
+//    are the next block of the sweep finishes them, multiplies them by that block's inverse and leaves y (x) of the next step behind; only
+//    the first step of a front computes its own.
+#define HS_SW_G 4                  // column groups per row
+#define HS_SW_GC (HS_SW / HS_SW_G)  // columns per group
+
+// partial sum of row `row` of inv * s_w over the columns of group jg (whole 32-blocks of the triangle)
+template <class T, bool LOWER>
+__device__ __forceinline__ T wide_inv_partial(const T* iv, int row, int jg, int wl, const T* s_w) {
+  T s = Scal<T>::zero();
+  if (row < wl) {
+    const int jlo = LOWER ? jg : max(row / HS_PB * HS_PB, jg);
+    const int jhi = LOWER ? min(min(wl, (row / HS_PB + 1) * HS_PB), jg + HS_SW_GC) : min(wl, jg + HS_SW_GC);
+    iv += row;
+#pragma unroll 32
+    for (int j = jlo; j < jhi; ++j) s = Scal<T>::fma(gld(iv + (size_t)j * HS_SW), s_w[j], s);
+  }
+  return s;
+}
+template <class T>
+__device__ __forceinline__ T wide_sum4(const T* s_red, int t) {
+  return (s_red[t] + s_red[t + HS_SW]) + (s_red[t + 2 * HS_SW] + s_red[t + 3 * HS_SW]);
+}
+
 // forward: y_blk = L[blk,blk]^-1 * w_blk ; rows below -= L[:, blk] * y_blk   (rows >= ni are the Abi*U^-1 rows: they update rhs[bnd])
 template <class T>
-__global__ __launch_bounds__(256) void fwd_wide_kernel(const SolveNode<T>* __restrict__ nodes, int blk, T* __restrict__ w, T* __restrict__ y,
-                                                       T* __restrict__ b) {
+__global__ __launch_bounds__(1024) void fwd_wide_kernel(const SolveNode<T>* __restrict__ nodes, int blk, T* __restrict__ w, T* __restrict__ y,
+                                                        T* __restrict__ b) {
   const SolveNode<T> nd = nodes[blockIdx.y];
   const int c0 = blk * HS_SW;
   if (c0 >= nd.ni) return;
   const int wl = min(HS_SW, nd.ni - c0);
   const int r0 = c0 + wl;
-  if (blockIdx.x > 0 && (int)blockIdx.x * 256 >= nd.mrows - r0) return;
+  if (blockIdx.x > 0 && (int)blockIdx.x * HS_SW >= nd.mrows - r0) return;
   __shared__ T s_w[HS_SW];
   __shared__ T s_y[HS_SW];
-  const int t = threadIdx.x;
-  s_w[t] = (t < wl) ? w[nd.woff + c0 + t] : Scal<T>::zero();
+  __shared__ T s_red[HS_SW * HS_SW_G];
+  const int t = threadIdx.x, row = t & (HS_SW - 1), g = t >> 8;  // g is wave-uniform
+  const int jg = g * HS_SW_GC;
+  const int r = r0 + blockIdx.x * HS_SW + row;
+  const bool mine = t < HS_SW && r < nd.mrows;
+  T wold = Scal<T>::zero();
+  int gi = 0;
+  if (mine) {  // issued ahead of the panel loads
+    if (r < nd.ni) {
+      wold = w[nd.woff + r];
+    } else {
+      gi = gld(nd.fidx + r);
+      wold = b[gi];
+    }
+  }
+  if (blk > 0) {  // left behind by the previous step
+    if (t < HS_SW) s_y[t] = (t < wl) ? y[nd.woff + c0 + t] : Scal<T>::zero();
+  } else {
+    if (t < HS_SW) s_w[t] = (t < wl) ? w[nd.woff + c0 + t] : Scal<T>::zero();
+    __syncthreads();
+    s_red[t] = wide_inv_partial<T, true>(nd.inv256L + (size_t)blk * HS_SW * HS_SW, row, jg, wl, s_w);
+    __syncthreads();
+    if (t < HS_SW) {
+      const T v = wide_sum4(s_red, t);
+      s_y[t] = v;
+      if (blockIdx.x == 0 && t < wl) y[nd.woff + c0 + t] = v;
+    }
+  }
   __syncthreads();
   {
-    const T* iv = nd.inv256L + (size_t)blk * HS_SW * HS_SW;
-    T s = Scal<T>::zero();
-    if (t < wl) {
-      const int jn = min(wl, (t / HS_PB + 1) * HS_PB);  // lower triangle, whole 32-blocks
-#pragma unroll 8
-      for (int j = 0; j < jn; ++j) s = Scal<T>::fma(iv[(size_t)t + (size_t)j * HS_SW], s_w[j], s);
+    T acc = Scal<T>::zero();
+    if (r < nd.mrows) {
+      const T* a = nd.LF + (size_t)r + (size_t)(c0 + jg) * nd.ldl;
+      const int jc = min(HS_SW_GC, wl - jg);
+#pragma unroll 32
+      for (int j = 0; j < jc; ++j) acc = Scal<T>::fma(gld(a + (size_t)j * nd.ldl), s_y[jg + j], acc);
     }
-    s_y[t] = s;
+    s_red[t] = acc;
   }
   __syncthreads();
-  if (blockIdx.x == 0 && t < wl) y[nd.woff + c0 + t] = s_y[t];
-  const int r = r0 + blockIdx.x * 256 + t;
-  if (r >= nd.mrows) return;
-  const T* a = nd.LF + (size_t)r + (size_t)c0 * nd.ldl;
-  T acc = Scal<T>::zero();
-#pragma unroll 8
-  for (int j = 0; j < wl; ++j) acc = Scal<T>::fma(a[(size_t)j * nd.ldl], s_y[j], acc);
-  if (r < nd.ni) {
-    w[nd.woff + r] = w[nd.woff + r] - acc;
-  } else {
-    const int g = nd.fidx[r];
-    b[g] = b[g] - acc;
+  T wnew = Scal<T>::zero();
+  if (mine) {
+    wnew = wold - wide_sum4(s_red, t);
+    if (r < nd.ni)
+      w[nd.woff + r] = wnew;
+    else
+      b[gi] = wnew;
   }
+  // the rows of this workgroup are the next block of the sweep: finish its step's product with the stored inverse
+  if (blockIdx.x != 0 || r0 >= nd.ni) return;
+  const int wl2 = min(HS_SW, nd.ni - r0);
+  __syncthreads();  // every thread has read s_red
+  if (t < HS_SW) s_w[t] = (t < wl2) ? wnew : Scal<T>::zero();
+  __syncthreads();
+  s_red[t] = wide_inv_partial<T, true>(nd.inv256L + (size_t)(blk + 1) * HS_SW * HS_SW, row, jg, wl2, s_w);
+  __syncthreads();
+  if (t < wl2) y[nd.woff + r0 + t] = wide_sum4(s_red, t);
 }
 
 // backward: x_blk = U[blk,blk]^-1 * w_blk ; rows above -= U[:, blk] * x_blk
 template <class T>
-__global__ __launch_bounds__(256) void bwd_wide_kernel(const SolveNode<T>* __restrict__ nodes, int blk, T* __restrict__ w, T* __restrict__ x) {
+__global__ __launch_bounds__(1024) void bwd_wide_kernel(const SolveNode<T>* __restrict__ nodes, int blk, T* __restrict__ w, T* __restrict__ x) {
   const SolveNode<T> nd = nodes[blockIdx.y];
   const int c0 = blk * HS_SW;
   if (c0 >= nd.ni) return;
   const int wl = min(HS_SW, nd.ni - c0);
-  if (blockIdx.x > 0 && (int)blockIdx.x * 256 >= c0) return;
+  if (blockIdx.x > 0 && (int)blockIdx.x * HS_SW >= c0) return;
+  const bool have_x = c0 + HS_SW < nd.ni;  // not the first step of this front's sweep: the step before left x_blk behind
+  if (have_x && c0 == 0) return;
   __shared__ T s_w[HS_SW];
   __shared__ T s_x[HS_SW];
-  const int t = threadIdx.x;
-  s_w[t] = (t < wl) ? w[nd.woff + c0 + t] : Scal<T>::zero();
-  __syncthreads();
-  {
-    const T* iv = nd.inv256U + (size_t)blk * HS_SW * HS_SW;
-    T s = Scal<T>::zero();
-    if (t < wl) {
-#pragma unroll 8
-      for (int j = t / HS_PB * HS_PB; j < wl; ++j) s = Scal<T>::fma(iv[(size_t)t + (size_t)j * HS_SW], s_w[j], s);  // upper triangle, whole 32-blocks
+  __shared__ T s_red[HS_SW * HS_SW_G];
+  const int t = threadIdx.x, row = t & (HS_SW - 1), g = t >> 8;
+  const int jg = g * HS_SW_GC;
+  const int r = blockIdx.x * HS_SW + row;
+  const bool mine = t < HS_SW && r < c0;
+  T wold = Scal<T>::zero();
+  if (mine) wold = w[nd.woff + r];
+  if (have_x) {
+    if (t < HS_SW) s_x[t] = x[nd.woff + c0 + t];
+  } else {
+    if (t < HS_SW) s_w[t] = (t < wl) ? w[nd.woff + c0 + t] : Scal<T>::zero();
+    __syncthreads();
+    s_red[t] = wide_inv_partial<T, false>(nd.inv256U + (size_t)blk * HS_SW * HS_SW, row, jg, wl, s_w);
+    __syncthreads();
+    if (t < HS_SW) {
+      const T v = wide_sum4(s_red, t);
+      s_x[t] = v;
+      if (blockIdx.x == 0 && t < wl) x[nd.woff + c0 + t] = v;
     }
-    s_x[t] = s;
   }
   __syncthreads();
-  if (blockIdx.x == 0 && t < wl) x[nd.woff + c0 + t] = s_x[t];
-  const int r = blockIdx.x * 256 + t;
-  if (r >= c0) return;
-  const T* a = nd.LF + (size_t)r + (size_t)c0 * nd.ldl;
-  T acc = Scal<T>::zero();
-#pragma unroll 8
-  for (int j = 0; j < wl; ++j) acc = Scal<T>::fma(a[(size_t)j * nd.ldl], s_x[j], acc);
-  w[nd.woff + r] = w[nd.woff + r] - acc;
+  {
+    T acc = Scal<T>::zero();
+    if (r < c0) {
+      const T* a = nd.LF + (size_t)r + (size_t)(c0 + jg) * nd.ldl;
+      const int jc = min(HS_SW_GC, wl - jg);
+#pragma unroll 32
+      for (int j = 0; j < jc; ++j) acc = Scal<T>::fma(gld(a + (size_t)j * nd.ldl), s_x[jg + j], acc);
+    }
+    s_red[t] = acc;
+  }
+  __syncthreads();
+  T wnew = Scal<T>::zero();
+  if (mine) {
+    wnew = wold - wide_sum4(s_red, t);
+    w[nd.woff + r] = wnew;
+  }
+  // rows [c0 - 256, c0) are the next block of the sweep
+  if ((int)blockIdx.x * HS_SW + HS_SW != c0) return;
+  __syncthreads();
+  if (t < HS_SW) s_w[t] = wnew;
+  __syncthreads();
+  s_red[t] = wide_inv_partial<T, false>(nd.inv256U + (size_t)(blk - 1) * HS_SW * HS_SW, row, jg, HS_SW, s_w);
+  __syncthreads();
+  if (t < HS_SW) x[nd.woff + c0 - HS_SW + t] = wide_sum4(s_red, t);
 }
 
 template <class T>
@@ -180,14 +264,14 @@ void launch_fwd_wide(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w
   if (nbatch <= 0) return;
   const int rows = maxm - blk * HS_SW;
   const int gx = rows > 0 ? (rows + 255) / 256 : 1;
-  hipLaunchKernelGGL(fwd_wide_kernel<T>, dim3(gx, nbatch), dim3(256), 0, s, dn, blk, w, y, b);
+  hipLaunchKernelGGL(fwd_wide_kernel<T>, dim3(gx, nbatch), dim3(HS_SW * HS_SW_G), 0, s, dn, blk, w, y, b);
 }
 template <class T>
 void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s) {
   if (nbatch <= 0) return;
   const int rows = blk * HS_SW;
   const int gx = rows > 0 ? (rows + 255) / 256 : 1;
-  hipLaunchKernelGGL(bwd_wide_kernel<T>, dim3(gx, nbatch), dim3(256), 0, s, dn, blk, w, x);
+  hipLaunchKernelGGL(bwd_wide_kernel<T>, dim3(gx, nbatch), dim3(HS_SW * HS_SW_G), 0, s, dn, blk, w, x);
 }
 int hs_solve_wide_cols() { return HS_SW; }
 
