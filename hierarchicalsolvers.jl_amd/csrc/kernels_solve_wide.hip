@@ -88,31 +88,66 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
 }
 
 // The sweeps below are chains of dependent launches (ni / 256 per front and sweep), so what matters for the large fronts is the latency of
-// one step, i.e. the number of dependent memory round trips in it (measured: 22 us per step whatever the size of the front).
-//  * A workgroup is 1024 threads = 256 rows x 4 column groups of 64: every thread has at most 64 loads, issued 32 at a time, and the four
-//    partial sums of a row meet in LDS (256 threads with one row each, loads dependent by eight: 74 us per forward step at Poisson 128^3).
+// one step, i.e. the number of dependent memory round trips in it (a step costs the same 22 us for 2 and for 127 workgroups).
+//  * A workgroup is 1024 threads over 256 rows.  Float64: a thread owns TWO adjacent rows and 32 columns, read as 32 16-byte loads that are
+//    all in flight at once -- one round trip for the 256 x 256 block; ComplexF64: one row and 64 columns.  The partial sums of a row meet
+//    in LDS.  (256 threads with one row each, loads dependent by eight: 74 us per forward step at Poisson 128^3.)
 //  * The product with the stored inverse of the diagonal block is taken OFF the chain of all workgroups but one: the workgroup whose rows
 //    are the next block of the sweep finishes them, multiplies them by that block's inverse and leaves y (x) of the next step behind; only
 //    the first step of a front computes its own.
-#define HS_SW_G 4                  // column groups per row
-#define HS_SW_GC (HS_SW / HS_SW_G)  // columns per group
+template <class T>
+struct WideCfg {
+  static constexpr int RP = sizeof(T) == 8 ? 2 : 1;  // rows per thread
+  static constexpr int NG = 1024 / (HS_SW / RP);     // column groups
+  static constexpr int GC = HS_SW / NG;              // columns per group
+};
 
-// partial sum of row `row` of inv * s_w over the columns of group jg (whole 32-blocks of the triangle)
-template <class T, bool LOWER>
-__device__ __forceinline__ T wide_inv_partial(const T* iv, int row, int jg, int wl, const T* s_w) {
-  T s = Scal<T>::zero();
-  if (row < wl) {
-    const int jlo = LOWER ? jg : max(row / HS_PB * HS_PB, jg);
-    const int jhi = LOWER ? min(min(wl, (row / HS_PB + 1) * HS_PB), jg + HS_SW_GC) : min(wl, jg + HS_SW_GC);
-    iv += row;
-#pragma unroll 32
-    for (int j = jlo; j < jhi; ++j) s = Scal<T>::fma(gld(iv + (size_t)j * HS_SW), s_w[j], s);
+// s[0..RP) += sum_{j in [jlo, jhi)} A[row + {0..RP}, j] * sv[j]; `a` points at (row, 0); nrows = how many of the thread's rows exist
+template <class T>
+__device__ __forceinline__ void wide_dot(const T* a, size_t ld, int jlo, int jhi, const T* sv, int nrows, T* s) {
+  if constexpr (WideCfg<T>::RP == 2) {
+    if (nrows == 2) {
+#pragma unroll 16
+      for (int j = jlo; j < jhi; ++j) {
+        const hs_d2u v = gld2(a + (size_t)j * ld);
+        const T y = sv[j];
+        s[0] = Scal<T>::fma(v.x, y, s[0]);
+        s[1] = Scal<T>::fma(v.y, y, s[1]);
+      }
+      return;
+    }
   }
-  return s;
+  if (nrows >= 1) {
+#pragma unroll 32
+    for (int j = jlo; j < jhi; ++j) s[0] = Scal<T>::fma(gld(a + (size_t)j * ld), sv[j], s[0]);
+  }
+}
+// thread coordinates: first row of the thread, first column of its group
+#define WIDE_COORDS                                                     \
+  constexpr int RP = WideCfg<T>::RP, NG = WideCfg<T>::NG, GC = WideCfg<T>::GC; \
+  const int t = threadIdx.x;                                            \
+  const int row = (t % (HS_SW / RP)) * RP, jg = (t / (HS_SW / RP)) * GC /* wave-uniform */
+template <class T>
+__device__ __forceinline__ void wide_put(T* s_red, int t, const T* s) {
+  constexpr int RP = WideCfg<T>::RP;
+  const int row = (t % (HS_SW / RP)) * RP, g = t / (HS_SW / RP);
+#pragma unroll
+  for (int q = 0; q < RP; ++q) s_red[g * HS_SW + row + q] = s[q];
 }
 template <class T>
-__device__ __forceinline__ T wide_sum4(const T* s_red, int t) {
-  return (s_red[t] + s_red[t + HS_SW]) + (s_red[t + 2 * HS_SW] + s_red[t + 3 * HS_SW]);
+__device__ __forceinline__ T wide_sum(const T* s_red, int t) {
+  T v = s_red[t];
+#pragma unroll
+  for (int g = 1; g < WideCfg<T>::NG; ++g) v = v + s_red[g * HS_SW + t];
+  return v;
+}
+// partial sums of inv * s_w for the thread's rows over the columns of its group (whole 32-blocks of the triangle)
+template <class T, bool LOWER>
+__device__ __forceinline__ void wide_inv_partial(const T* iv, int row, int jg, int wl, const T* s_w, T* s) {
+  constexpr int RP = WideCfg<T>::RP, GC = WideCfg<T>::GC;
+  const int jlo = LOWER ? jg : max(row / HS_PB * HS_PB, jg);
+  const int jhi = LOWER ? min(min(wl, (row / HS_PB + 1) * HS_PB), jg + GC) : min(wl, jg + GC);
+  wide_dot<T>(iv + row, HS_SW, jlo, jhi, s_w, min(RP, wl - row), s);
 }
 
 // forward: y_blk = L[blk,blk]^-1 * w_blk ; rows below -= L[:, blk] * y_blk   (rows >= ni are the Abi*U^-1 rows: they update rhs[bnd])
@@ -127,10 +162,10 @@ __global__ __launch_bounds__(1024) void fwd_wide_kernel(const SolveNode<T>* __re
   if (blockIdx.x > 0 && (int)blockIdx.x * HS_SW >= nd.mrows - r0) return;
   __shared__ T s_w[HS_SW];
   __shared__ T s_y[HS_SW];
-  __shared__ T s_red[HS_SW * HS_SW_G];
-  const int t = threadIdx.x, row = t & (HS_SW - 1), g = t >> 8;  // g is wave-uniform
-  const int jg = g * HS_SW_GC;
-  const int r = r0 + blockIdx.x * HS_SW + row;
+  __shared__ T s_red[HS_SW * WideCfg<T>::NG];
+  WIDE_COORDS;
+  const int rbase = r0 + blockIdx.x * HS_SW;
+  const int r = rbase + t;  // the row thread t < 256 finishes
   const bool mine = t < HS_SW && r < nd.mrows;
   T wold = Scal<T>::zero();
   int gi = 0;
@@ -147,29 +182,27 @@ __global__ __launch_bounds__(1024) void fwd_wide_kernel(const SolveNode<T>* __re
   } else {
     if (t < HS_SW) s_w[t] = (t < wl) ? w[nd.woff + c0 + t] : Scal<T>::zero();
     __syncthreads();
-    s_red[t] = wide_inv_partial<T, true>(nd.inv256L + (size_t)blk * HS_SW * HS_SW, row, jg, wl, s_w);
+    T s[RP] = {};
+    wide_inv_partial<T, true>(nd.inv256L + (size_t)blk * HS_SW * HS_SW, row, jg, wl, s_w, s);
+    wide_put<T>(s_red, t, s);
     __syncthreads();
     if (t < HS_SW) {
-      const T v = wide_sum4(s_red, t);
+      const T v = wide_sum<T>(s_red, t);
       s_y[t] = v;
       if (blockIdx.x == 0 && t < wl) y[nd.woff + c0 + t] = v;
     }
+    __syncthreads();  // s_red is written again below
   }
   __syncthreads();
   {
-    T acc = Scal<T>::zero();
-    if (r < nd.mrows) {
-      const T* a = nd.LF + (size_t)r + (size_t)(c0 + jg) * nd.ldl;
-      const int jc = min(HS_SW_GC, wl - jg);
-#pragma unroll 32
-      for (int j = 0; j < jc; ++j) acc = Scal<T>::fma(gld(a + (size_t)j * nd.ldl), s_y[jg + j], acc);
-    }
-    s_red[t] = acc;
+    T s[RP] = {};
+    wide_dot<T>(nd.LF + (size_t)(rbase + row) + (size_t)c0 * nd.ldl, nd.ldl, jg, min(jg + GC, wl), s_y, min(RP, nd.mrows - (rbase + row)), s);
+    wide_put<T>(s_red, t, s);
   }
   __syncthreads();
   T wnew = Scal<T>::zero();
   if (mine) {
-    wnew = wold - wide_sum4(s_red, t);
+    wnew = wold - wide_sum<T>(s_red, t);
     if (r < nd.ni)
       w[nd.woff + r] = wnew;
     else
@@ -181,9 +214,13 @@ __global__ __launch_bounds__(1024) void fwd_wide_kernel(const SolveNode<T>* __re
   __syncthreads();  // every thread has read s_red
   if (t < HS_SW) s_w[t] = (t < wl2) ? wnew : Scal<T>::zero();
   __syncthreads();
-  s_red[t] = wide_inv_partial<T, true>(nd.inv256L + (size_t)(blk + 1) * HS_SW * HS_SW, row, jg, wl2, s_w);
+  {
+    T s[RP] = {};
+    wide_inv_partial<T, true>(nd.inv256L + (size_t)(blk + 1) * HS_SW * HS_SW, row, jg, wl2, s_w, s);
+    wide_put<T>(s_red, t, s);
+  }
   __syncthreads();
-  if (t < wl2) y[nd.woff + r0 + t] = wide_sum4(s_red, t);
+  if (t < wl2) y[nd.woff + r0 + t] = wide_sum<T>(s_red, t);
 }
 
 // backward: x_blk = U[blk,blk]^-1 * w_blk ; rows above -= U[:, blk] * x_blk
@@ -198,10 +235,10 @@ __global__ __launch_bounds__(1024) void bwd_wide_kernel(const SolveNode<T>* __re
   if (have_x && c0 == 0) return;
   __shared__ T s_w[HS_SW];
   __shared__ T s_x[HS_SW];
-  __shared__ T s_red[HS_SW * HS_SW_G];
-  const int t = threadIdx.x, row = t & (HS_SW - 1), g = t >> 8;
-  const int jg = g * HS_SW_GC;
-  const int r = blockIdx.x * HS_SW + row;
+  __shared__ T s_red[HS_SW * WideCfg<T>::NG];
+  WIDE_COORDS;
+  const int rbase = blockIdx.x * HS_SW;
+  const int r = rbase + t;
   const bool mine = t < HS_SW && r < c0;
   T wold = Scal<T>::zero();
   if (mine) wold = w[nd.woff + r];
@@ -210,39 +247,41 @@ __global__ __launch_bounds__(1024) void bwd_wide_kernel(const SolveNode<T>* __re
   } else {
     if (t < HS_SW) s_w[t] = (t < wl) ? w[nd.woff + c0 + t] : Scal<T>::zero();
     __syncthreads();
-    s_red[t] = wide_inv_partial<T, false>(nd.inv256U + (size_t)blk * HS_SW * HS_SW, row, jg, wl, s_w);
+    T s[RP] = {};
+    wide_inv_partial<T, false>(nd.inv256U + (size_t)blk * HS_SW * HS_SW, row, jg, wl, s_w, s);
+    wide_put<T>(s_red, t, s);
     __syncthreads();
     if (t < HS_SW) {
-      const T v = wide_sum4(s_red, t);
+      const T v = wide_sum<T>(s_red, t);
       s_x[t] = v;
       if (blockIdx.x == 0 && t < wl) x[nd.woff + c0 + t] = v;
     }
+    __syncthreads();
   }
   __syncthreads();
   {
-    T acc = Scal<T>::zero();
-    if (r < c0) {
-      const T* a = nd.LF + (size_t)r + (size_t)(c0 + jg) * nd.ldl;
-      const int jc = min(HS_SW_GC, wl - jg);
-#pragma unroll 32
-      for (int j = 0; j < jc; ++j) acc = Scal<T>::fma(gld(a + (size_t)j * nd.ldl), s_x[jg + j], acc);
-    }
-    s_red[t] = acc;
+    T s[RP] = {};
+    wide_dot<T>(nd.LF + (size_t)(rbase + row) + (size_t)c0 * nd.ldl, nd.ldl, jg, min(jg + GC, wl), s_x, min(RP, c0 - (rbase + row)), s);
+    wide_put<T>(s_red, t, s);
   }
   __syncthreads();
   T wnew = Scal<T>::zero();
   if (mine) {
-    wnew = wold - wide_sum4(s_red, t);
+    wnew = wold - wide_sum<T>(s_red, t);
     w[nd.woff + r] = wnew;
   }
   // rows [c0 - 256, c0) are the next block of the sweep
-  if ((int)blockIdx.x * HS_SW + HS_SW != c0) return;
+  if (rbase + HS_SW != c0) return;
   __syncthreads();
   if (t < HS_SW) s_w[t] = wnew;
   __syncthreads();
-  s_red[t] = wide_inv_partial<T, false>(nd.inv256U + (size_t)(blk - 1) * HS_SW * HS_SW, row, jg, HS_SW, s_w);
+  {
+    T s[RP] = {};
+    wide_inv_partial<T, false>(nd.inv256U + (size_t)(blk - 1) * HS_SW * HS_SW, row, jg, HS_SW, s_w, s);
+    wide_put<T>(s_red, t, s);
+  }
   __syncthreads();
-  if (t < HS_SW) x[nd.woff + c0 - HS_SW + t] = wide_sum4(s_red, t);
+  if (t < HS_SW) x[nd.woff + c0 - HS_SW + t] = wide_sum<T>(s_red, t);
 }
 
 template <class T>
@@ -264,14 +303,14 @@ void launch_fwd_wide(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w
   if (nbatch <= 0) return;
   const int rows = maxm - blk * HS_SW;
   const int gx = rows > 0 ? (rows + 255) / 256 : 1;
-  hipLaunchKernelGGL(fwd_wide_kernel<T>, dim3(gx, nbatch), dim3(HS_SW * HS_SW_G), 0, s, dn, blk, w, y, b);
+  hipLaunchKernelGGL(fwd_wide_kernel<T>, dim3(gx, nbatch), dim3(1024), 0, s, dn, blk, w, y, b);
 }
 template <class T>
 void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s) {
   if (nbatch <= 0) return;
   const int rows = blk * HS_SW;
   const int gx = rows > 0 ? (rows + 255) / 256 : 1;
-  hipLaunchKernelGGL(bwd_wide_kernel<T>, dim3(gx, nbatch), dim3(HS_SW * HS_SW_G), 0, s, dn, blk, w, x);
+  hipLaunchKernelGGL(bwd_wide_kernel<T>, dim3(gx, nbatch), dim3(1024), 0, s, dn, blk, w, x);
 }
 int hs_solve_wide_cols() { return HS_SW; }
 
