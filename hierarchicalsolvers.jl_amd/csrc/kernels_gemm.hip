@@ -206,38 +206,11 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
     if (more) load_tile(k0 + BK);
     const double* a_rd = smem + cur * STAGE + a_off;
     const double* b_rd = smem + cur * STAGE + b_off;
-#ifndef HS_GEMM_CHAINED
-    // Interleaved issue: with VGPR accumulators (-amdgpu-mfma-vgpr-form) independent v_mfma_f64_16x16x4_f64 issue every 64 cycles, while a
-    // MFMA that reads the accumulator the previous one wrote waits ~10 cycles for it (74 cycles/MFMA in chains of 4, tools/mfma_f64_probe.hip)
-    // -- and the partner wave of the SIMD cannot use a bubble shorter than one MFMA.  So each k-step of the tile visits all 16 accumulators.
-    {
-      double af[2][4], bf[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[0][j] = b_rd[(j * 16) * LDB_S];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[0][i] = a_rd[i * 16];
-#pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        const int c = ks & 1, n = c ^ 1;
-        if (ks + 1 < BK / 4) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bf[n][j] = b_rd[(j * 16) * LDB_S + (ks + 1) * 4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) af[n][i] = a_rd[((ks + 1) * 4) * LDS_LD + i * 16];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            // transposed issue: MFMA-A <- B data (n on the register/row axis), MFMA-B <- A data (m on lane&15)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[c][j], af[c][i], acc[i][j], 0, 0, 0);
-      }
-    }
-#else
     // Chained issue: v_mfma_f64_16x16x4_f64 pays ~40 extra cycles whenever consecutive MFMAs use a
     // different accumulator (C read + D write through the register file); back-to-back MFMAs on the
     // SAME accumulator forward it inside the pipe (measured: 105 -> 74 cycles/MFMA at chain 4,
     // tools/mfma_f64_probe.hip).  So every accumulator takes all BK/4 k-steps of the tile in a row.
+    // (Round 2: visiting all 16 accumulators per k-step instead measured the same -- 63.6 vs 64.4 TFLOP/s at 8192^3.)
     {
       double bf[4][BK / 4];
 #pragma unroll
@@ -268,7 +241,6 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
         }
       }
     }
-#endif
     if (more) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
