@@ -138,6 +138,10 @@ struct NodeH {
   bool mf = false;             // both children hand over HSS Schur complements: the front is never assembled densely
   void* S_hss = nullptr;       // hs_hss*: S[perm, perm], perm = [int_loc; bnd_loc], first split at n1p
   int n1p = 0;                 // |int_loc|: boundary DOFs of this node that become interior at the parent
+  bool mfd = false;            // matrix-free front whose interior block D = Aii is expanded and eliminated DENSELY (hs_options.mf == 1 and not an
+                               // hss_d front): S, Aib, Abi still travel as generators; buffers sized by the generators' ranks, per factorization
+  void *mfd_LF = nullptr, *mfd_UR = nullptr, *mfd_SB = nullptr;
+  int mfd_nbp = 0, mfd_ldl = 0, mfd_ldu = 0;
   int last_ks = 0;             // samples the previous compression of S ended with
   std::vector<int64_t> sperm;  // [int_loc; bnd_loc] as 0-based positions in this node's boundary
   struct Coupling {            // entries of a sparse coupling block in block coordinates; e = position in nzval
@@ -239,6 +243,7 @@ static inline size_t rups(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static void free_lowrank_any(hs_handle* h);
 static void free_hss_any(hs_handle* h);
+static void free_mfd_buffers(hs_handle* h);
 static void free_handle(hs_handle* h) {
   if (!h) return;
   for (auto& x : h->nodes)
@@ -246,6 +251,7 @@ static void free_handle(hs_handle* h) {
       hs_hss_free((hs_hss*)x.S_hss);
       x.S_hss = nullptr;
     }
+  free_mfd_buffers(h);
   free_hss_any(h);
   free_lowrank_any(h);
   void* ptrs[] = {h->d_fac,   h->d_inv, h->d_sb,    h->d_int, h->d_tmpi, h->d_colptr, h->d_rowval, h->d_nz,
@@ -556,6 +562,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         NodeH& x = N[i];
         if (!x.mf) continue;
         h->mf_on = true;
+        x.mfd = opts.mf == 1 && !x.hssd;  // mf == 2: D of every matrix-free front is an HSS matrix (the reference's formulation)
         x.hssd = false;  // the matrix-free form supersedes hs_options.hss_d
         x.ilv = hss_bisect_perm(h->fidx_host.data() + x.off_fidx, x.ni, n, colptr, rowval, where);
       }
@@ -620,6 +627,18 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           x.off_ipiv = x.off_rperm = ints;
           x.off_cand = tmpi;
           x.woff = woff;
+          if (x.mfd) {  // dense D: what its LU and the sweeps of ldiv! need besides the matrix itself (allocated per factorization)
+            const int nblk = (x.ni + HS_PB - 1) / HS_PB;
+            inv += (size_t)2 * nblk * HS_PB * HS_PB;
+            x.off_inv256 = inv;
+            inv += (size_t)2 * ((x.ni + 255) / 256) * 256 * 256;
+            ints += x.ni;
+            x.off_rperm = ints;
+            ints += x.ni;
+            x.ncand = ((x.ni + HS_CHUNK - 1) / HS_CHUNK + 1) * HS_PB;
+            tmpi += (size_t)2 * x.ncand + HS_PB;
+            woff += x.ni;
+          }
           continue;
         }
         x.off_LF = fac;
@@ -886,6 +905,7 @@ template <class T>
 static void numeric_begin(hs_handle* h, const void* nzval, int on_device) {
   if (!nzval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: nzval == NULL");
   hipStream_t s = h->stream;
+  free_mfd_buffers(h);
   free_hss_nodes<T>(h);
   free_mf_nodes<T>(h);
   free_lowrank_nodes<T>(h);
@@ -1035,6 +1055,7 @@ static void numeric_end(hs_handle* h) {
       if (x.hss) dyn += (double)hs_hss_bytes((const hs_hss*)x.hss);
       if (x.S_hss) dyn += (double)hs_hss_bytes((const hs_hss*)x.S_hss);
       if (x.hW) dyn += (double)x.hldw * std::max(x.last_rR, 0) * esz;
+      if (x.mfd_LF) dyn += ((double)x.mfd_ldl * x.ni + (double)x.mfd_ldu * x.mfd_nbp) * esz;  // dense D with Z_L*U^-1 below it, L^-1*P*C_R
       dyn += ((double)x.nb + x.ni) * (std::max(x.last_rL, 0) + std::max(x.last_rR, 0)) * esz * ((x.lrL || x.lrR) ? 1.0 : 0.0);
     }
     h->stats.bytes_factors = h->static_factor_bytes + dyn;

@@ -268,6 +268,8 @@ template <class T>
 void launch_perm_gather(const T* src, const int64_t* perm, T* dst, int64_t cnt, hipStream_t s);
 template <class T>
 void launch_transpose(const T* in, int ldi, T* out, int ldo, int rows, int cols, hipStream_t s);
+template <class T>
+void launch_negate(T* A, int ld, int rows, int cols, hipStream_t s);
 
 void hs_set_error(int code, long long info, const char* fmt, ...);
 

@@ -296,7 +296,7 @@ static void solve_lr_fwd(hs_handle* h, int lv, T* db, hipStream_t s) {
   T* w2 = (T*)h->d_w2;  // y = L11^-1 P rhs[int]
   for (int id : L.mine) {
     const NodeH& x = h->nodes[id];
-    if (!x.compressed || !x.lrL || x.hssd || x.mf) continue;
+    if (!(x.compressed || x.mfd) || !x.lrL || x.hssd || (x.mf && !x.mfd)) continue;
     const LowRank<T>& lr = *(const LowRank<T>*)x.lrL;
     if (lr.r == 0) continue;
     ensure_lr_workspace<T>(h, lr.r, lr.cols);
@@ -312,7 +312,7 @@ static void solve_lr_bwd(hs_handle* h, int lv, T* db, hipStream_t s) {
   T* w1 = (T*)h->d_w1;
   for (int id : L.mine) {
     const NodeH& x = h->nodes[id];
-    if (!x.compressed || !x.lrR || x.hssd || x.mf) continue;
+    if (!(x.compressed || x.mfd) || !x.lrR || x.hssd || (x.mf && !x.mfd)) continue;
     const LowRank<T>& lr = *(const LowRank<T>*)x.lrR;
     if (lr.r == 0) continue;
     ensure_lr_workspace<T>(h, lr.r, lr.cols);

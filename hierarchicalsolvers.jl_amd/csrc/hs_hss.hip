@@ -260,6 +260,30 @@ struct Pool {
       for (auto& pr : v) (void)hipFree(pr.first);
     }
     v.clear();
+    zcur = nullptr;
+    zleft = 0;
+  }
+  // Zero-filled scratch carved out of chunks that are cleared with ONE memset when they are taken: the per-node buffers of a grouped
+  // stage (hundreds per tree level) used to cost a memset launch each -- 64,000 of the 172,000 launches of a matrix-free factorization of
+  // Poisson 128^3.  Everything a Pool hands out is used on one stream, after the chunk's memset in stream order.
+  char* zcur = nullptr;
+  size_t zleft = 0;
+  template <class U>
+  U* getz(size_t count, hipStream_t s) {
+    const size_t bytes = (count * sizeof(U) + 511) / 256 * 256;
+    if (bytes > zleft) {
+      const size_t chunk = std::max(bytes, (size_t)16 << 20);
+      zcur = (char*)get<char>(chunk);
+      zleft = chunk;
+      if (hipMemsetAsync(zcur, 0, chunk, s) != hipSuccess) {
+        hs_set_error(HS_ERR_DEVICE, 0, "hipMemsetAsync failed (HSS module)");
+        throw (int)HS_ERR_DEVICE;
+      }
+    }
+    U* p = (U*)zcur;
+    zcur += bytes;
+    zleft -= bytes;
+    return p;
   }
   template <class U>
   U* get(size_t count) {
@@ -751,7 +775,7 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     S.ldl = ev(J.rmax);
     S.Q = tmp.get<T>((size_t)S.ldq * J.q);
     S.Qh = tmp.get<T>((size_t)S.ldqh * J.rmax);
-    S.L = tmp.get<T>((size_t)S.ldl * J.rmax);
+    S.L = tmp.getz<T>((size_t)S.ldl * J.rmax, s);
     S.W = tmp.get<T>((size_t)HS_QW * J.q);
     S.Wh = tmp.get<T>((size_t)S.ldqh * HS_QW);
     S.C1 = tmp.get<T>((size_t)HS_QW * J.rmax);
@@ -762,7 +786,6 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     S.lperm = tmp.get<int>(HS_QW);
     S.nslab = J.rmax / (HS_QW / 2) + 8;
     S.slab = tmp.get<T>((size_t)S.nslab * 2 * HS_QW * HS_QW);
-    HSS_HIP(hipMemsetAsync(S.L, 0, sizeof(T) * (size_t)S.ldl * J.rmax, s));
   }
   int* dnacc = tmp.get<int>((size_t)nj);
   for (int a = 0; a < nj; ++a) st[a].nacc = dnacc + a;
@@ -788,7 +811,7 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       each([&](int, QrJob<T>& J, St& S, int b) {
         if (S.done == 0) return;
         T* Cx = pass == 0 ? S.C1 : S.C2;
-        HSS_HIP(hipMemsetAsync(Cx, 0, sizeof(T) * (size_t)HS_QW * S.done, s));
+        // (C = A*B overwrites the b x done block that is read: no memset per window)
         g.push_back(GemmProb<T>{S.W, S.Qh, Cx, b, S.done, J.q, HS_QW, S.ldqh, HS_QW});
       });
       run_gemms(tmp, g, 0, s);
@@ -806,7 +829,6 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     run_subs(tmp, subs, s);
     std::vector<CholJob<T>> cj;
     each([&](int a, QrJob<T>& J, St& S, int b) {
-      HSS_HIP(hipMemsetAsync(S.G, 0, sizeof(T) * HS_QW * HS_QW, s));
       g.push_back(GemmProb<T>{S.W, S.Wh, S.G, b, b, J.q, HS_QW, S.ldqh, HS_QW});
       T* slot = S.used < S.nslab ? S.slab + (size_t)(S.used++) * 2 * HS_QW * HS_QW : tmp.get<T>(2 * HS_QW * HS_QW);
       linv[a].push_back(slot);
@@ -824,7 +846,6 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     each([&](int a, QrJob<T>& J, St& S, int b) {
       const int na = hacc[a];
       if (na <= 0) return;
-      HSS_HIP(hipMemset2DAsync(S.Q + S.done, sizeof(T) * S.ldq, 0, sizeof(T) * na, J.q, s));
       g.push_back(GemmProb<T>{linvp[a].back(), S.W, S.Q + S.done, na, J.q, b, HS_QW, HS_QW, S.ldq});
       if (S.done > 0) rows.push_back(RowJob<T>{S.C1, HS_QW, S.L + S.done, S.ldl, S.lperm, na, S.done, ROW_GATHER});
     });
@@ -895,7 +916,6 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       if (nR <= 0 || step >= nb_) continue;
       const int bi = nb_ - 1 - step, j0 = S.blocks[bi].first, w = S.blocks[bi].second, j1 = j0 + w;
       if (r > j1) g1.push_back(GemmProb<T>{J.Tm + (size_t)j1 * J.ldt, S.L + j1 + (size_t)j0 * S.ldl, J.Tm + (size_t)j0 * J.ldt, nR, w, r - j1, J.ldt, S.ldl, J.ldt});
-      HSS_HIP(hipMemsetAsync(T2[a], 0, sizeof(T) * (size_t)ev(nR) * HS_QW, s));
       g2.push_back(GemmProb<T>{J.Tm + (size_t)j0 * J.ldt, linv[a][bi], T2[a], nR, w, w, J.ldt, HS_QW, ev(nR)});
       back.push_back(SubJob<T>{T2[a], ev(nR), nullptr, nullptr, 0, 0, nR, w, J.Tm + (size_t)j0 * J.ldt, J.ldt, 0});
     }
@@ -961,8 +981,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       if (!j.trans) {
         T* Cg = tmp.get<T>((size_t)ev(j.rows) * r1);
         T* Zg = tmp.get<T>((size_t)ev(r2) * j.cols);
-        T* T1 = tmp.get<T>((size_t)ev(j.rows) * r2);
-        HSS_HIP(hipMemsetAsync(T1, 0, sizeof(T) * (size_t)ev(j.rows) * r2, s));
+        T* T1 = tmp.getz<T>((size_t)ev(j.rows) * r2, s);
         pieces.push_back(SubJob<T>{lru.C, lru.ldc, j.ri, nullptr, j.r0, 0, j.rows, r1, Cg, ev(j.rows), 0});
         pieces.push_back(SubJob<T>{lru.Z, lru.ldz, nullptr, j.ci, 0, j.c0, r2, j.cols, Zg, ev(r2), 0});
         g1.push_back(GemmProb<T>{Cg, lru.M, T1, j.rows, r2, r1, ev(j.rows), lru.ldm, ev(j.rows)});
@@ -970,8 +989,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       } else {  // out is cols x rows:  out -= Z[:, J]^T * (M^T * C[I, :]^T)
         T* CgT = tmp.get<T>((size_t)ev(r1) * j.rows);
         T* ZgT = tmp.get<T>((size_t)ev(j.cols) * r2);
-        T* T1T = tmp.get<T>((size_t)ev(r2) * j.rows);
-        HSS_HIP(hipMemsetAsync(T1T, 0, sizeof(T) * (size_t)ev(r2) * j.rows, s));
+        T* T1T = tmp.getz<T>((size_t)ev(r2) * j.rows, s);
         pieces.push_back(SubJob<T>{lru.C, lru.ldc, j.ri, nullptr, j.r0, 0, j.rows, r1, CgT, ev(r1), 1});
         pieces.push_back(SubJob<T>{lru.Z, lru.ldz, nullptr, j.ci, 0, j.c0, r2, j.cols, ZgT, ev(j.cols), 1});
         g1.push_back(GemmProb<T>{MT, CgT, T1T, r2, j.rows, r1, ev(r2), ev(r1), ev(r2)});
@@ -1391,15 +1409,32 @@ void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q, bool trans
     return;
   }
   // upward pass: XT[i] = [x~_left; x~_right] of every inner node
-  std::vector<T*> XT(N, nullptr), G(N, nullptr);
+  std::vector<T*> XT(N, nullptr), G(N, nullptr), TD(N, nullptr);
   std::vector<int> ldx_(N, 0);
-  for (int i = 0; i < N; ++i)
-    if (nd[i].left >= 0) {
-      ldx_[i] = ev(nd[i].m);
-      XT[i] = tmp.get<T>((size_t)ldx_[i] * q);
-      G[i] = tmp.get<T>((size_t)ldx_[i] * q);
-      HSS_HIP(hipMemsetAsync(G[i], 0, sizeof(T) * (size_t)ldx_[i] * q, s));
+  {  // everything that must start from zero comes out of ONE block cleared by ONE memset: the products of a tree level are grouped
+     // launches, but a memset per node made an application of the matrix hundreds of launches (expanding a 32,768 block from its
+     // generators, 32 applications: 50,000 memsets)
+    size_t zel = 0;
+    for (int i = 0; i < N; ++i) {
+      if (nd[i].left >= 0) zel += (size_t)ev(nd[i].m) * q;
+      if (i != 0 && nd[i].m - nd[i].r > 0) zel += (size_t)ev(nd[i].m - nd[i].r) * q;
     }
+    T* z = tmp.get<T>(zel + 2);
+    HSS_HIP(hipMemsetAsync(z, 0, sizeof(T) * zel, s));
+    for (int i = 0; i < N; ++i) {
+      if (nd[i].left >= 0) {
+        ldx_[i] = ev(nd[i].m);
+        XT[i] = tmp.get<T>((size_t)ldx_[i] * q);
+        G[i] = z;
+        z += (size_t)ldx_[i] * q;
+      }
+      if (i != 0 && nd[i].m - nd[i].r > 0) {
+        TD[i] = z;
+        z += (size_t)ev(nd[i].m - nd[i].r) * q;
+      }
+    }
+    HSS_HIP(hipMemset2DAsync(Y, sizeof(T) * ldy, 0, sizeof(T) * H.n, q, s));  // the leaves' output blocks tile Y
+  }
   for (int lv = H.nlev - 1; lv >= 1; --lv) {
     for (int i : H.lev[lv]) {
       const HNode<T>& x = nd[i];
@@ -1427,7 +1462,6 @@ void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q, bool trans
       if (x.left < 0) {
         blk = Y + x.lo;
         ldb = ldy;
-        HSS_HIP(hipMemset2DAsync(blk, sizeof(T) * ldy, 0, sizeof(T) * x.m, q, s));
         gemms.push_back(GemmProb<T>{trans ? x.DTt : x.D, X + x.lo, blk, x.m, q, x.m, x.ldd, ldx, ldy});
       } else {
         blk = G[i];
@@ -1446,8 +1480,7 @@ void hss_mul_p(HssT<T>& H, const T* X, int ldx, T* Y, int ldy, int q, bool trans
         const T* g = G[par] + x.off_in_parent;
         adds.push_back(RowJob<T>{g, ldx_[par], blk, ldb, x.p, r, q, ROW_SCATTER_ADD});
         if (nR > 0) {
-          T* t = tmp.get<T>((size_t)ev(nR) * q);
-          HSS_HIP(hipMemsetAsync(t, 0, sizeof(T) * (size_t)ev(nR) * q, s));
+          T* t = TD[i];
           gemms.push_back(GemmProb<T>{x.Tm, g, t, nR, q, r, x.ldt, ldx_[par], ev(nR)});
           adds.push_back(RowJob<T>{t, ev(nR), blk, ldb, x.p + r, nR, q, ROW_SCATTER_ADD});
         }
@@ -1555,8 +1588,7 @@ void hss_basis(HssT<T>& H, int node, T* out, int ldo) {
       }
       const int cl = nd[x.left].hi - nd[x.left].lo, cr = cnt - cl, rl = nd[x.left].r, rr = nd[x.right].r;
       const int ldw = ev(cnt);
-      T* W = tmp.get<T>((size_t)ldw * x.m);
-      HSS_HIP(hipMemsetAsync(W, 0, sizeof(T) * (size_t)ldw * x.m, s));
+      T* W = tmp.getz<T>((size_t)ldw * x.m, s);
       blocks.push_back(SubJob<T>{E[x.left], lde[x.left], nullptr, nullptr, 0, 0, cl, rl, W, ldw, 0});
       blocks.push_back(SubJob<T>{E[x.right], lde[x.right], nullptr, nullptr, 0, 0, cr, rr, W + cl + (size_t)ldw * rl, ldw, 0});
       cg.push_back(SubJob<T>{W, ldw, nullptr, x.p, 0, 0, cnt, rk, E[i], lde[i], 0});

@@ -201,8 +201,7 @@ void hss_getindex_batch(HssT<T>& H, const std::vector<GiJob<T>>& jobs) {
     prep(g.I, g.ni, js[b].sI, js[b].oI);
     prep(g.J, g.nj, js[b].sJ, js[b].oJ);
     js[b].ldS = ev(g.ni);
-    js[b].outS = tmp.get<T>((size_t)js[b].ldS * g.nj);
-    HSS_HIP(hipMemsetAsync(js[b].outS, 0, sizeof(T) * (size_t)js[b].ldS * g.nj, s));
+    js[b].outS = tmp.getz<T>((size_t)js[b].ldS * g.nj, s);
     nints += (size_t)4 * (g.ni + g.nj);
   }
   IntArena ia;
@@ -302,14 +301,12 @@ void hss_getindex_batch(HssT<T>& H, const std::vector<GiJob<T>>& jobs) {
         const int ldS = js[b].ldS;
         // out[I_l, J_r] = E_l * B12 * F_r,  out[I_r, J_l] = E_r * B21 * F_l
         if (cIl > 0 && cJr > 0 && rl > 0 && rr > 0) {
-          T* t = tmp.get<T>((size_t)ev(cIl) * rr);
-          HSS_HIP(hipMemsetAsync(t, 0, sizeof(T) * (size_t)ev(cIl) * rr, s));
+          T* t = tmp.getz<T>((size_t)ev(cIl) * rr, s);
           ga.push_back(GemmProb<T>{E[at(b, l)], x.B12, t, cIl, rr, rl, ev(cIl), x.ld12, ev(cIl)});
           gb.push_back(GemmProb<T>{t, F[at(b, r)], outS + bI[at(b, l)] + (size_t)ldS * bJ[at(b, r)], cIl, cJr, rr, ev(cIl), ev(rr), ldS});
         }
         if (cIr > 0 && cJl > 0 && rl > 0 && rr > 0) {
-          T* t = tmp.get<T>((size_t)ev(cIr) * rl);
-          HSS_HIP(hipMemsetAsync(t, 0, sizeof(T) * (size_t)ev(cIr) * rl, s));
+          T* t = tmp.getz<T>((size_t)ev(cIr) * rl, s);
           ga.push_back(GemmProb<T>{E[at(b, r)], x.B21, t, cIr, rl, rr, ev(cIr), x.ld21, ev(cIr)});
           gb.push_back(GemmProb<T>{t, F[at(b, l)], outS + bI[at(b, r)] + (size_t)ldS * bJ[at(b, l)], cIr, cJl, rl, ev(cIr), ev(rl), ldS});
         }
@@ -322,8 +319,7 @@ void hss_getindex_batch(HssT<T>& H, const std::vector<GiJob<T>>& jobs) {
         const int cI = cIl + cIr, cJ = cJl + cJr;
         if (cI > 0) {
           const int ldw = ev(cI);
-          T* W = tmp.get<T>((size_t)ldw * m);
-          HSS_HIP(hipMemsetAsync(W, 0, sizeof(T) * (size_t)ldw * m, s));
+          T* W = tmp.getz<T>((size_t)ldw * m, s);
           if (cIl > 0) blocks.push_back(SubJob<T>{E[at(b, l)], ev(cIl), nullptr, nullptr, 0, 0, cIl, rl, W, ldw, 0});
           if (cIr > 0) blocks.push_back(SubJob<T>{E[at(b, r)], ev(cIr), nullptr, nullptr, 0, 0, cIr, rr, W + cIl + (size_t)ldw * rl, ldw, 0});
           T* Ei = E[at(b, i)] = tmp.get<T>((size_t)ldw * rk);
@@ -336,8 +332,7 @@ void hss_getindex_batch(HssT<T>& H, const std::vector<GiJob<T>>& jobs) {
         }
         if (cJ > 0) {
           const int ldw = ev(m);
-          T* Wt = tmp.get<T>((size_t)ldw * cJ);
-          HSS_HIP(hipMemsetAsync(Wt, 0, sizeof(T) * (size_t)ldw * cJ, s));
+          T* Wt = tmp.getz<T>((size_t)ldw * cJ, s);
           if (cJl > 0) blocks.push_back(SubJob<T>{F[at(b, l)], ev(rl), nullptr, nullptr, 0, 0, rl, cJl, Wt, ldw, 0});
           if (cJr > 0) blocks.push_back(SubJob<T>{F[at(b, r)], ev(rr), nullptr, nullptr, 0, 0, rr, cJr, Wt + rl + (size_t)ldw * cJl, ldw, 0});
           T* Fi = F[at(b, i)] = tmp.get<T>((size_t)ev(rk) * cJ);

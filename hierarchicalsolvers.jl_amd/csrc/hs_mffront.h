@@ -129,6 +129,24 @@ static void free_mf_nodes(hs_handle* h) {
   }
 }
 
+// a matrix-free front with a dense interior block (NodeH::mfd): D with Z_L*U^-1 below it, L^-1*P*C_R and the small Schur block are
+// allocated per factorization; its low-rank objects borrow the two factors that live inside those buffers
+static void free_mfd_buffers(hs_handle* h) {
+  for (auto& x : h->nodes) {
+    if (!x.mfd_LF && !x.mfd_UR && !x.mfd_SB) continue;
+    if (x.lrL) {
+      if (h->is_complex) ((LowRank<cplx>*)x.lrL)->Z = nullptr; else ((LowRank<double>*)x.lrL)->Z = nullptr;
+    }
+    if (x.lrR) {
+      if (h->is_complex) ((LowRank<cplx>*)x.lrR)->Cd = nullptr; else ((LowRank<double>*)x.lrR)->Cd = nullptr;
+    }
+    if (x.mfd_LF) (void)hipFree(x.mfd_LF);
+    if (x.mfd_UR) (void)hipFree(x.mfd_UR);
+    if (x.mfd_SB) (void)hipFree(x.mfd_SB);
+    x.mfd_LF = x.mfd_UR = x.mfd_SB = nullptr;
+  }
+}
+
 static hs_hss_options mf_options(const hs_handle* h, int node, double scale, int64_t first_split, int last_k, int n) {
   hs_hss_options o;
   hs_hss_options_default(&o);
@@ -340,27 +358,6 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
     std::vector<int64_t> gid((size_t)x.m);
     for (int p = 0; p < x.m; ++p) gid[(size_t)p] = h->fidx_host[x.off_fidx + p];
     MfBuf<T> buf;
-    // ---- D = Aii as one HSS matrix, compressed from the operator [S1.A11 A[int1,int2]; A[int2,int1] S2.A11] ------------------------------
-    {
-      hs_hss_blockop op{ch1.n1, ch2.n1, ch1.a11, ch2.a11, gid.data(), &As, (int32_t*)h->d_lpos};
-      hs_hss_options o = mf_options(h, id, dsc, 0, x.last_k, x.ni);
-      hs_hss* D = nullptr;
-      const int64_t* q = x.ilv.empty() ? nullptr : x.ilv.data();
-      mf_check(h->is_complex ? hs_hss_compress_blockop_z(&op, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, q, &o, s, &D)
-                             : hs_hss_compress_blockop_d(&op, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, q, &o, s, &D));
-      x.hss = D;
-      lap("D: compress(Aii) matrix-free");
-      int st = hs_hss_factor(D);
-      if (st != 0) {
-        if (st == HS_ERR_SINGULAR) hs_set_error(HS_ERR_SINGULAR, id, "SingularException: the HSS form of the interior block of node %d is singular", id);
-        throw HsError{st};
-      }
-      lap("D: HSS elimination");
-      x.last_k = (int)hs_hss_samples(D);
-      mf_maxrank(h, hs_hss_rank(D));
-      if (say) fprintf(stderr, "[hs] node %d (level %d, ni=%d, nb=%d): hssrank(D)=%lld (%lld samples), matrix-free\n", id, x.level, x.ni, x.nb, (long long)hs_hss_rank(D), (long long)hs_hss_samples(D));
-      if (!x.ht) dmalloc(&x.ht, ((size_t)x.ni + 32) * sizeof(T), "HSS solve vector");
-    }
     // the children's Schur complements are released once absorbed (the reference keeps every S although only the root's is used)
     auto release_children = [&]() {
       if (h->opts.keep_schur) return;
@@ -370,75 +367,207 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
       hs_hss_free((hs_hss*)c2.S_hss);
       c1.S_hss = c2.S_hss = nullptr;
     };
-    if (x.nb == 0) {
-      release_children();
-      return;
-    }
-    // ---- Aib = C_R*Z_R and Abi = C_L*Z_L from the children's generators + the sparse couplings (nothing is recompressed) -------------------
+    // ---- Aib = C_R*Z_R and Abi = C_L*Z_L from the children's generators + the sparse couplings (nothing is recompressed): ranks ------------
     std::vector<HsFillEntry> fcR, fzR, fcL, fzL;
-    const int oR1 = 0, oR2 = ch1.r12, oRx = ch1.r12 + ch2.r12;
-    const int rR = oRx + mf_factor_coupling(x.xr, oRx, fcR, fzR);
-    const int oL1 = 0, oL2 = ch1.r21, oLx = ch1.r21 + ch2.r21;
-    const int rL = oLx + mf_factor_coupling(x.xl, oLx, fcL, fzL);
-    (void)oR1; (void)oL1;
-    LowRank<T>* lrL = new LowRank<T>();
-    LowRank<T>* lrR = new LowRank<T>();
-    x.lrL = lrL;
-    x.lrR = lrR;
-    lrL->rows = x.nb; lrL->cols = x.ni; lrL->r = rL; lrL->k = rL;
-    lrR->rows = x.ni; lrR->cols = x.nb; lrR->r = rR; lrR->k = rR;
-    lrL->ldc = rup(std::max(x.nb, 1), 2); lrL->ldz = rup(std::max(rL, 1), 2);
-    lrR->ldc = rup(std::max(x.ni, 1), 2); lrR->ldz = rup(std::max(rR, 1), 2);
+    const int oR2 = ch1.r12, oRx = ch1.r12 + ch2.r12;
+    const int rR = x.nb > 0 ? oRx + mf_factor_coupling(x.xr, oRx, fcR, fzR) : 0;
+    const int oL2 = ch1.r21, oLx = ch1.r21 + ch2.r21;
+    const int rL = x.nb > 0 ? oLx + mf_factor_coupling(x.xl, oLx, fcL, fzL) : 0;
+    LowRank<T>*lrL = nullptr, *lrR = nullptr;
     auto zalloc = [&](T** p, size_t elems, const char* what) {
       dmalloc((void**)p, (elems + 32) * sizeof(T), what);
       HS_HIP(hipMemsetAsync(*p, 0, (elems + 32) * sizeof(T), s));
     };
-    zalloc(&lrL->Cd, (size_t)lrL->ldc * std::max(rL, 1), "C_L");
-    zalloc(&lrL->Z, (size_t)lrL->ldz * std::max(x.ni, 1), "Z_L");
-    zalloc(&lrR->Cd, (size_t)lrR->ldc * std::max(rR, 1), "C_R");
-    zalloc(&lrR->Z, (size_t)lrR->ldz * std::max(x.nb, 1), "Z_R");
+    if (x.nb > 0) {
+      lrL = new LowRank<T>();
+      lrR = new LowRank<T>();
+      x.lrL = lrL;
+      x.lrR = lrR;
+      lrL->rows = x.nb; lrL->cols = x.ni; lrL->r = rL; lrL->k = rL;
+      lrR->rows = x.ni; lrR->cols = x.nb; lrR->r = rR; lrR->k = rR;
+      lrL->ldc = rup(std::max(x.nb, 1), 2);
+      lrR->ldz = rup(std::max(rR, 1), 2);
+      zalloc(&lrL->Cd, (size_t)lrL->ldc * std::max(rL, 1), "C_L");
+      zalloc(&lrR->Z, (size_t)lrR->ldz * std::max(x.nb, 1), "Z_R");
+      x.last_rL = rL;
+      x.last_rR = rR;
+      mf_maxrank(h, std::max(rL, rR));
+      if (say)
+        fprintf(stderr, "[hs] node %d (level %d, ni=%d, nb=%d): rank(L)=%d (%d+%d from the children, %d sparse) rank(R)=%d (%d+%d, %d sparse)\n", id, x.level, x.ni,
+                x.nb, rL, ch1.r21, ch2.r21, rL - oLx, rR, ch1.r12, ch2.r12, rR - oRx);
+    }
     auto offd = [&](MfChild& c, int which, T* Cp, int ldc, T* Zp, int ldz) {
       if (c.n1 == 0 || c.n2 == 0) return;
       mf_check(hs_hss_set_stream(c.S, (void*)s));
       mf_check(hs_hss_offdiag(c.S, which, (double*)Cp, ldc, (double*)Zp, ldz, 1));
     };
-    // Aib: rows int, columns bnd;  block (1,1) = A12 of S1, block (2,2) = A12 of S2
-    offd(ch1, 0, lrR->Cd, lrR->ldc, lrR->Z, lrR->ldz);
-    offd(ch2, 0, lrR->Cd + ch1.n1 + (size_t)oR2 * lrR->ldc, lrR->ldc, lrR->Z + oR2 + (size_t)ch1.n2 * lrR->ldz, lrR->ldz);
-    // Abi: rows bnd, columns int;  block (1,1) = A21 of S1, block (2,2) = A21 of S2
-    offd(ch1, 1, lrL->Cd, lrL->ldc, lrL->Z, lrL->ldz);
-    offd(ch2, 1, lrL->Cd + ch1.n2 + (size_t)oL2 * lrL->ldc, lrL->ldc, lrL->Z + oL2 + (size_t)ch1.n1 * lrL->ldz, lrL->ldz);
-    mf_fill<T>(h, fcR, lrR->Cd, lrR->ldc, buf, s);
-    mf_fill<T>(h, fzR, lrR->Z, lrR->ldz, buf, s);
-    mf_fill<T>(h, fcL, lrL->Cd, lrL->ldc, buf, s);
-    mf_fill<T>(h, fzL, lrL->Z, lrL->ldz, buf, s);
-    x.last_rL = rL;
-    x.last_rR = rR;
-    mf_maxrank(h, std::max(rL, rR));
-    if (say)
-      fprintf(stderr, "[hs] node %d (level %d, ni=%d, nb=%d): rank(L)=%d (%d+%d from the children, %d sparse) rank(R)=%d (%d+%d, %d sparse)\n", id, x.level, x.ni,
-              x.nb, rL, ch1.r21, ch2.r21, rL - oLx, rR, ch1.r12, ch2.r12, rR - oRx);
-    lap("Aib, Abi from the generators");
-    // ---- W = Aii^-1 * C_R (the R transform; C_R itself is not needed again) ---------------------------------------------------------------------
-    T* Mm = nullptr;
+    // fills C_L, Z_R (owned by the low-rank objects) and Z_L (rL x ni), C_R (ni x rR) wherever the formulation of D wants them
+    auto generators = [&](T* ZL, int ldzl, T* CR, int ldcr) {
+      if (x.nb == 0) return;
+      // Aib: rows int, columns bnd;  block (1,1) = A12 of S1, block (2,2) = A12 of S2
+      offd(ch1, 0, CR, ldcr, lrR->Z, lrR->ldz);
+      offd(ch2, 0, CR + ch1.n1 + (size_t)oR2 * ldcr, ldcr, lrR->Z + oR2 + (size_t)ch1.n2 * lrR->ldz, lrR->ldz);
+      // Abi: rows bnd, columns int;  block (1,1) = A21 of S1, block (2,2) = A21 of S2
+      offd(ch1, 1, lrL->Cd, lrL->ldc, ZL, ldzl);
+      offd(ch2, 1, lrL->Cd + ch1.n2 + (size_t)oL2 * lrL->ldc, lrL->ldc, ZL + oL2 + (size_t)ch1.n1 * ldzl, ldzl);
+      mf_fill<T>(h, fcR, CR, ldcr, buf, s);
+      mf_fill<T>(h, fzR, lrR->Z, lrR->ldz, buf, s);
+      mf_fill<T>(h, fcL, lrL->Cd, lrL->ldc, buf, s);
+      mf_fill<T>(h, fzL, ZL, ldzl, buf, s);
+    };
+    T* Mm = nullptr;  // Abi*R = C_L * M * Z_R, M = Z_L * Aii^-1 * C_R  (rL x rR)
     int ldm = 2;
-    if (rR > 0) {
-      mf_check(hs_hss_set_stream((hs_hss*)x.hss, (void*)s));
-      mf_check(hs_hss_ldiv((hs_hss*)x.hss, (double*)lrR->Cd, lrR->ldc, rR, 1));
-      x.hW = lrR->Cd;  // ownership moves to the node (freed with the HSS objects); the low-rank object keeps only Z_R
-      x.hldw = lrR->ldc;
-      lrR->Cd = nullptr;
-      lap("W = D^-1 C_R");
-      if (rL > 0) {  // M = Z_L * W  (rL x rR):  Abi*R = C_L * M * Z_R
-        ldm = rup(rL, 2);
-        Mm = buf.get((size_t)ldm * rR, "Z_L*W");
-        HS_HIP(hipMemsetAsync(Mm, 0, sizeof(T) * (size_t)ldm * rR, s));
-        GemmProb<T> gp{lrL->Z, (const T*)x.hW, Mm, rL, rR, x.ni, lrL->ldz, x.hldw, ldm};
-        GemmProb<T>* dgp = (GemmProb<T>*)buf.get((sizeof(GemmProb<T>) + sizeof(T) - 1) / sizeof(T), "GEMM descriptor");
-        HS_HIP(hipMemcpyAsync(dgp, &gp, sizeof gp, hipMemcpyHostToDevice, s));
+    hs_hss_blockop opd{ch1.n1, ch2.n1, ch1.a11, ch2.a11, gid.data(), &As, (int32_t*)h->d_lpos};
+    if (x.mfd) {
+      // ---- D = Aii expanded from the operator [S1.A11 A[int1,int2]; A[int2,int1] S2.A11] and eliminated DENSELY ---------------------------------
+      // The front [D C_R; Z_L 0] of size ni + max(rL, rR) is an ordinary front for the elimination kernels: its LU leaves Z_L*U^-1 below D,
+      // L^-1*P*C_R beside it and -M in the corner -- the low-rank Gauss transforms in the form hs_compress.h applies in ldiv!.
+      const int nbp = std::max(2, rup(std::max(rL, rR), 2));
+      const int m = x.ni + nbp, ldl = rup(m, 2), ldu = rup(std::max(x.ni, 1), 2), ldsb = nbp;
+      dmalloc(&x.mfd_LF, ((size_t)ldl * x.ni + 32) * sizeof(T), "dense interior block of a matrix-free front");
+      dmalloc(&x.mfd_UR, ((size_t)ldu * nbp + 32) * sizeof(T), "L^-1*P*C_R of a matrix-free front");
+      dmalloc(&x.mfd_SB, ((size_t)ldsb * nbp + 32) * sizeof(T), "Z_L*Aii^-1*C_R of a matrix-free front");
+      x.mfd_nbp = nbp; x.mfd_ldl = ldl; x.mfd_ldu = ldu;
+      T *LF = (T*)x.mfd_LF, *UR = (T*)x.mfd_UR, *SB = (T*)x.mfd_SB;
+      const LevelH& L = h->levels[x.level];
+      NodeDesc<T>* dslot = (NodeDesc<T>*)h->d_nodes + L.desc_off + x.batch_pos;
+      SolveNode<T>* sslot = (SolveNode<T>*)h->d_solve + L.desc_off + x.batch_pos;
+      T* dinv = (T*)h->d_inv;
+      const int nblk = (x.ni + HS_PB - 1) / HS_PB;
+      NodeDesc<T> d;
+      memset(&d, 0, sizeof d);
+      d.LF = LF; d.UR = UR; d.SB = SB;
+      d.invL = dinv + x.off_inv;
+      d.invU = d.invL + (size_t)nblk * HS_PB * HS_PB;
+      d.inv256L = dinv + x.off_inv256;
+      d.inv256U = d.inv256L + (size_t)((x.ni + 255) / 256) * 256 * 256;
+      d.ipiv = h->d_int + x.off_ipiv;
+      d.rperm = h->d_int + x.off_rperm;
+      d.cand0 = h->d_tmpi + x.off_cand;
+      d.cand1 = d.cand0 + x.ncand;
+      d.pivlist = d.cand1 + x.ncand;
+      d.info = h->d_info + id;
+      d.growth = h->d_growth + id;
+      d.fidx = h->d_int + x.off_fidx;
+      d.ni = x.ni; d.nb = nbp; d.m = m;
+      d.ldl = ldl; d.ldu = ldu; d.lds = ldsb;
+      d.ni1 = x.ni; d.nb1 = nbp;
+      d.isleaf = 1;
+      d.node = id;
+      d.finalize();
+      SolveNode<T> q;
+      memset(&q, 0, sizeof q);
+      q.LF = LF; q.UR = UR; q.invL = d.invL; q.invU = d.invU; q.inv256L = d.inv256L; q.inv256U = d.inv256U;
+      q.rperm = d.rperm; q.fidx = d.fidx;
+      q.ni = x.ni; q.nb = 0; q.m = x.ni; q.ldl = ldl; q.ldu = ldu;
+      q.compressed = 1;
+      q.mrows = x.ni;
+      q.woff = x.woff;
+      HS_HIP(hipMemcpyAsync(dslot, &d, sizeof d, hipMemcpyHostToDevice, s));
+      HS_HIP(hipMemcpyAsync(sslot, &q, sizeof q, hipMemcpyHostToDevice, s));
+      HS_HIP(hipStreamSynchronize(s));  // d, q are stack objects
+      const int cb = 1024, ldi = rup(x.ni, 2);
+      T* I_ = buf.get((size_t)ldi * cb, "identity block");
+      const bool lone = (s == h->stream);  // the look-ahead streams belong to the handle: only a front that runs alone may use them
+      Profiler prof;                       // h->prof is not shared between concurrent fronts
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        HS_HIP(hipMemsetAsync(LF, 0, ((size_t)ldl * x.ni + 32) * sizeof(T), s));
+        HS_HIP(hipMemsetAsync(UR, 0, ((size_t)ldu * nbp + 32) * sizeof(T), s));
+        HS_HIP(hipMemsetAsync(SB, 0, ((size_t)ldsb * nbp + 32) * sizeof(T), s));
+        for (int c0 = 0; c0 < x.ni; c0 += cb) {
+          const int nc = std::min(cb, x.ni - c0);
+          launch_identity_cols<T>(I_, ldi, x.ni, c0, nc, s);
+          mf_check(hs_hss_blockop_apply(&opd, h->is_complex, (const double*)I_, ldi, (double*)(LF + (size_t)c0 * ldl), ldl, nc, 0, s));
+        }
+        generators(LF + x.ni, ldl, UR, ldu);
+        if (attempt == 0) lap("D: Aii expanded from the generators; Aib, Abi");
+        launch_init_fronts<T>(dslot, 1, m, s);
+        bool opt;
+        {
+          std::lock_guard<std::mutex> lk(g_mf_mu);
+          opt = h->optimistic;
+        }
+        static const bool opt_env = !(getenv("HS_OPTIMISTIC") && getenv("HS_OPTIMISTIC")[0] == '0');
+        opt = opt && opt_env && attempt == 0;
+        int hni = x.ni, hnb = nbp;
+        Sched<T> sch{dslot, 1, x.ni, nbp, m, s, &prof, &hni, &hnb, lone ? h->stream2 : nullptr, 0, lone ? h->stream_la : nullptr, lone ? h->stream2m : nullptr};
+        sch.sn = sslot;
+        sch.optimistic = opt;
+        sch.factor_fronts();
+        if (!opt) break;
+        int gr = 0;
+        HS_HIP(hipMemcpyAsync(&gr, h->d_growth + id, sizeof(int), hipMemcpyDeviceToHost, s));
         HS_HIP(hipStreamSynchronize(s));
-        launch_gemm_probs<T>(dgp, 1, rL, rR, 0, s);
+        if (gr == 0) break;
+        {
+          std::lock_guard<std::mutex> lk(g_mf_mu);
+          h->optimistic = false;
+        }
+        if (h->opts.verbose) fprintf(stderr, "[hs] node %d: a pivot outside the diagonal block was needed; redoing its interior block with tournament pivoting\n", id);
       }
+      lap("D: dense elimination");
+      if (x.nb > 0) {
+        launch_negate<T>(SB, ldsb, rL, rR, s);  // the elimination left Abb - Abi*Aii^-1*Aib = -M in the corner
+        Mm = SB;
+        ldm = ldsb;
+        lrL->Z = LF + x.ni;  // Z_L*U^-1 (borrowed: free_mfd_buffers)
+        lrL->ldz = ldl;
+        lrR->Cd = UR;        // L^-1*P*C_R (borrowed)
+        lrR->ldc = ldu;
+      }
+    } else {
+      // ---- D = Aii as one HSS matrix, compressed from the operator [S1.A11 A[int1,int2]; A[int2,int1] S2.A11] ------------------------------
+      {
+        hs_hss_options o = mf_options(h, id, dsc, 0, x.last_k, x.ni);
+        hs_hss* D = nullptr;
+        const int64_t* q = x.ilv.empty() ? nullptr : x.ilv.data();
+        mf_check(h->is_complex ? hs_hss_compress_blockop_z(&opd, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, q, &o, s, &D)
+                               : hs_hss_compress_blockop_d(&opd, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, q, &o, s, &D));
+        x.hss = D;
+        lap("D: compress(Aii) matrix-free");
+        int st = hs_hss_factor(D);
+        if (st != 0) {
+          if (st == HS_ERR_SINGULAR) hs_set_error(HS_ERR_SINGULAR, id, "SingularException: the HSS form of the interior block of node %d is singular", id);
+          throw HsError{st};
+        }
+        lap("D: HSS elimination");
+        x.last_k = (int)hs_hss_samples(D);
+        mf_maxrank(h, hs_hss_rank(D));
+        if (say) fprintf(stderr, "[hs] node %d (level %d, ni=%d, nb=%d): hssrank(D)=%lld (%lld samples), matrix-free\n", id, x.level, x.ni, x.nb, (long long)hs_hss_rank(D), (long long)hs_hss_samples(D));
+        if (!x.ht) dmalloc(&x.ht, ((size_t)x.ni + 32) * sizeof(T), "HSS solve vector");
+      }
+      if (x.nb > 0) {
+        lrL->ldz = rup(std::max(rL, 1), 2);
+        lrR->ldc = rup(std::max(x.ni, 1), 2);
+        zalloc(&lrL->Z, (size_t)lrL->ldz * std::max(x.ni, 1), "Z_L");
+        zalloc(&lrR->Cd, (size_t)lrR->ldc * std::max(rR, 1), "C_R");
+        generators(lrL->Z, lrL->ldz, lrR->Cd, lrR->ldc);
+        lap("Aib, Abi from the generators");
+        // ---- W = Aii^-1 * C_R (the R transform; C_R itself is not needed again) -------------------------------------------------------------------
+        if (rR > 0) {
+          mf_check(hs_hss_set_stream((hs_hss*)x.hss, (void*)s));
+          mf_check(hs_hss_ldiv((hs_hss*)x.hss, (double*)lrR->Cd, lrR->ldc, rR, 1));
+          x.hW = lrR->Cd;  // ownership moves to the node (freed with the HSS objects); the low-rank object keeps only Z_R
+          x.hldw = lrR->ldc;
+          lrR->Cd = nullptr;
+          lap("W = D^-1 C_R");
+          if (rL > 0) {  // M = Z_L * W  (rL x rR):  Abi*R = C_L * M * Z_R
+            ldm = rup(rL, 2);
+            Mm = buf.get((size_t)ldm * rR, "Z_L*W");
+            HS_HIP(hipMemsetAsync(Mm, 0, sizeof(T) * (size_t)ldm * rR, s));
+            GemmProb<T> gp{lrL->Z, (const T*)x.hW, Mm, rL, rR, x.ni, lrL->ldz, x.hldw, ldm};
+            GemmProb<T>* dgp = (GemmProb<T>*)buf.get((sizeof(GemmProb<T>) + sizeof(T) - 1) / sizeof(T), "GEMM descriptor");
+            HS_HIP(hipMemcpyAsync(dgp, &gp, sizeof gp, hipMemcpyHostToDevice, s));
+            HS_HIP(hipStreamSynchronize(s));
+            launch_gemm_probs<T>(dgp, 1, rL, rR, 0, s);
+          }
+        }
+      }
+    }
+    if (x.nb == 0) {
+      HS_HIP(hipStreamSynchronize(s));
+      release_children();
+      return;
     }
     const bool upd = rL > 0 && rR > 0;
     // ---- S = P (Abb - Abi*R) P' from products and entries of the operator [S1.A22 A[bnd1,bnd2]; A[bnd2,bnd1] S2.A22] - C_L*M*Z_R ----------

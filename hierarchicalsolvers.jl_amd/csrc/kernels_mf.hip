@@ -61,10 +61,26 @@ void launch_transpose(const T* in, int ldi, T* out, int ldo, int rows, int cols,
   hipLaunchKernelGGL(transpose_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, in, ldi, out, ldo, rows, cols);
 }
 
+// A (rows x cols, ld) = -A
+template <class T>
+__global__ __launch_bounds__(256) void negate_kernel(T* __restrict__ A, int ld, int rows, int cols) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)rows * cols) return;
+  T* p = A + (size_t)(i % rows) + (size_t)(i / rows) * ld;
+  *p = -*p;
+}
+template <class T>
+void launch_negate(T* A, int ld, int rows, int cols, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return;
+  const size_t tot = (size_t)rows * cols;
+  hipLaunchKernelGGL(negate_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, ld, rows, cols);
+}
+
 #define INST(T)                                                                                              \
   template void launch_fill_entries<T>(const HsFillEntry*, int, const T*, T*, int, hipStream_t);           \
   template void launch_identity_cols<T>(T*, int, int, int, int, hipStream_t);                               \
   template void launch_perm_gather<T>(const T*, const int64_t*, T*, int64_t, hipStream_t);                  \
-  template void launch_transpose<T>(const T*, int, T*, int, int, int, hipStream_t);
+  template void launch_transpose<T>(const T*, int, T*, int, int, int, hipStream_t);                        \
+  template void launch_negate<T>(T*, int, int, int, hipStream_t);
 INST(double)
 INST(cplx)

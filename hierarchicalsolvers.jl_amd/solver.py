@@ -44,7 +44,9 @@ class SolverOptions:
         self.split_size = 0  # columns per slice of a compressed front's interior block (multiple of 256, 0 = off)
         self.hss_min = 0  # > 0 (multiple of 1024): compressed-level fronts with at least this many interior DOFs keep D as HSS
         self.hss_dexp = None  # orders of magnitude by which the HSS form of D is tighter than atol, rtol (None: 2; 0: the same)
-        self.mf = False  # matrix-free compressed branch: S leaves flagged fronts as HSS, parents assemble from the children's generators
+        # matrix-free compressed branch: S leaves flagged fronts as HSS, parents assemble from the children's generators.  True / 'dense': the
+        # interior block D of such a parent is expanded and eliminated densely (HSS only where hss_min says so); 2 / 'hss': D is an HSS matrix
+        self.mf = False
         self._set(kw)
 
     def _set(self, kw):
@@ -78,7 +80,14 @@ class SolverOptions:
         if hm < 0 or hm % 1024 or hm // 1024 > 255:
             raise ValueError("hss_min must be a multiple of 1024 in 0:261120")
         o.hss_d = hm // 1024
-        o.mf = 1 if self.mf else 0
+        if self.mf in (False, None, 0):
+            o.mf = 0
+        elif self.mf in (True, 1, "dense"):
+            o.mf = 1  # interior blocks of the matrix-free fronts dense unless hss_min asks for HSS
+        elif self.mf in (2, "hss"):
+            o.mf = 2  # every interior block an HSS matrix (the reference's formulation)
+        else:
+            raise ValueError("mf must be False, True / 'dense' or 2 / 'hss'")
         if self.hss_dexp is not None:
             if not 0 <= int(self.hss_dexp) <= 12:
                 raise ValueError("hss_dexp must be in 0:12")

@@ -68,11 +68,15 @@ typedef struct hs_options {
   uint8_t hss_dexp;   /* tolerance of that HSS form: atol, rtol * 10^-e with e = 2 for hss_dexp = 0 (default) and e = hss_dexp - 1
                          otherwise (1: the tolerance of the fronts, as the reference does).  D^-1 inherits cond(D) * tol, the low-rank
                          couplings only tol: measured on Poisson 128^3 the same tolerance for both leaves GMRES unconverged */
-  uint8_t mf;         /* 1: the compressed branch with the reference's data flow (src/factorization.jl:78-112,126-140): the Schur complement of a
+  uint8_t mf;         /* 1 or 2: the compressed branch with the reference's data flow (src/factorization.jl:78-112,126-140): the Schur complement of a
                          flagged front leaves as an HSS matrix compressed from the operator Abb - Abi*R (never formed where the children are HSS),
-                         a parent with two such children is assembled matrix-free from their generators and the sparse couplings of A -- no dense
-                         front, D = Aii one HSS matrix compressed from its operator, L / R from the children's generators (hs_mffront.h).
-                         Single rank only; hss_dexp sets the tolerance of D; hs_maxrank includes hssrank(S). */
+                         a parent with two such children is assembled matrix-free from their generators and the sparse couplings of A: Aib, Abi
+                         and Abb are never dense, L / R come from the children's generators (hs_mffront.h).
+                         2: D = Aii of such a parent is ONE HSS matrix compressed from its operator, like the reference's (hss_dexp sets its tolerance).
+                         1: D is expanded from the generators and eliminated densely by the front kernels (ni x ni, the one dense block of the
+                            front), except on the fronts hss_d selects: the dense LU of a 32,768 block takes 0.5 s, its HSS compression +
+                            elimination at 1e-4 1.8 s.
+                         Single rank only; hs_maxrank includes hssrank(S). */
   uint8_t reserved[1];
   int64_t seed;       /* RNG seed of the randomized compression (reference: Random.seed!(123), test/rungmres.jl:7) */
 } hs_options;
