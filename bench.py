@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--split", type=int, default=0, help="slice width (multiple of 256) in which compressed fronts eliminate their interior block; 0 = off")
     ap.add_argument("--hss-min", type=int, default=0, help="fronts of the compressed levels with at least this many interior DOFs (multiple of 1024) keep D = Aii as an HSS matrix; 0 = dense LU of D")
     ap.add_argument("--hss-dexp", type=int, default=None, help="orders of magnitude by which the HSS form of D is tighter than --tol (default 2)")
-    ap.add_argument("--mf", nargs="?", const=1, default=0, type=int, help="matrix-free compressed branch: S travels between the compressed fronts as HSS matrices (the reference's data flow); 1 = interior blocks of those fronts dense (unless --hss-min), 2 = HSS like the reference's")
+    ap.add_argument("--mf", nargs="?", const=1, default=0, type=int, help="matrix-free compressed branch: S travels between the compressed fronts as HSS matrices (the reference's data flow); 1 = interior blocks of those fronts dense (unless --hss-min), 2 = one HSS matrix, 3 = the reference's 2x2 block factorization over HSS blocks")
     ap.add_argument("--leafsize", type=int, default=32, help="SolverOptions.leafsize (HSS leaves; the device uses at least 128)")
     args = ap.parse_args()
 

@@ -148,7 +148,14 @@ struct NodeH {
     std::vector<int> row, col;
     std::vector<long long> e;
     size_t size() const { return row.size(); }
-  } xr, xl;                    // A[int, bnd] / A[bnd, int] between the two children's parts (matrix-free fronts)
+  } xr, xl,                    // A[int, bnd] / A[bnd, int] between the two children's parts (matrix-free fronts)
+      x12, x21;                // A[int1, int2] / A[int2, int1] in block coordinates (the 2x2 block form of D, hs_options.mf == 3)
+  // hs_options.mf == 3: D = blockfactor([A11 A12; A21 A22]) over HSS blocks (src/blockmatrix.jl:121-130) -- hss = A11 (a view of the left
+  // child's Schur complement, kept alive in hss_keep), hss2 = S22 = A22 - A21*A11^-1*A12 recompressed, A12 = C12*Z12 and A21 = C21*Z21 exactly
+  bool mfb = false;
+  void *hss2 = nullptr, *hss_keep = nullptr;
+  void *bW12 = nullptr, *bZ12 = nullptr, *bC21 = nullptr, *bZ21 = nullptr;  // A11^-1*C12 (n1 x k12), Z12 (k12 x n2), C21 (n2 x k21), Z21 (k21 x n1)
+  int bk12 = 0, bk21 = 0, bldw = 0, bldz12 = 0, bldc21 = 0, bldz21 = 0;
 };
 
 struct LevelH {
@@ -562,7 +569,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         NodeH& x = N[i];
         if (!x.mf) continue;
         h->mf_on = true;
-        x.mfd = opts.mf == 1 && !x.hssd;  // mf == 2: D of every matrix-free front is an HSS matrix (the reference's formulation)
+        x.mfd = opts.mf == 1 && !x.hssd;  // mf == 2: D of every matrix-free front is ONE HSS matrix; mf == 3: the reference's 2x2 block form
+        x.mfb = opts.mf == 3;
         x.hssd = false;  // the matrix-free form supersedes hs_options.hss_d
         x.ilv = hss_bisect_perm(h->fidx_host.data() + x.off_fidx, x.ni, n, colptr, rowval, where);
       }

@@ -572,7 +572,7 @@ struct Lru {
   const T* M = nullptr;
   const T* Z = nullptr;
   int ldc = 0, ldm = 0, ldz = 0, r1 = 0, r2 = 0;
-  bool on() const { return C && M && Z && r1 > 0 && r2 > 0; }
+  bool on() const { return C && Z && r1 > 0 && r2 > 0; }  // M == nullptr: the identity (r1 == r2)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -958,7 +958,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
   std::vector<RowJob<T>> rows;
   std::vector<GemmProb<T>> gemms;
   T* MT = nullptr;  // M^T for the transposed gathers
-  if (lru.on()) {
+  if (lru.on() && lru.M) {
     MT = tmp.get<T>((size_t)ev(lru.r2) * lru.r1);
     std::vector<SubJob<T>> one{SubJob<T>{lru.M, lru.ldm, nullptr, nullptr, 0, 0, lru.r1, lru.r2, MT, ev(lru.r2), 1}};
     run_subs(tmp, one, s);
@@ -981,18 +981,18 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       if (!j.trans) {
         T* Cg = tmp.get<T>((size_t)ev(j.rows) * r1);
         T* Zg = tmp.get<T>((size_t)ev(r2) * j.cols);
-        T* T1 = tmp.getz<T>((size_t)ev(j.rows) * r2, s);
+        T* T1 = lru.M ? tmp.getz<T>((size_t)ev(j.rows) * r2, s) : Cg;
         pieces.push_back(SubJob<T>{lru.C, lru.ldc, j.ri, nullptr, j.r0, 0, j.rows, r1, Cg, ev(j.rows), 0});
         pieces.push_back(SubJob<T>{lru.Z, lru.ldz, nullptr, j.ci, 0, j.c0, r2, j.cols, Zg, ev(r2), 0});
-        g1.push_back(GemmProb<T>{Cg, lru.M, T1, j.rows, r2, r1, ev(j.rows), lru.ldm, ev(j.rows)});
+        if (lru.M) g1.push_back(GemmProb<T>{Cg, lru.M, T1, j.rows, r2, r1, ev(j.rows), lru.ldm, ev(j.rows)});
         g2.push_back(GemmProb<T>{T1, Zg, j.out, j.rows, j.cols, r2, ev(j.rows), ev(r2), j.ldo});
       } else {  // out is cols x rows:  out -= Z[:, J]^T * (M^T * C[I, :]^T)
         T* CgT = tmp.get<T>((size_t)ev(r1) * j.rows);
         T* ZgT = tmp.get<T>((size_t)ev(j.cols) * r2);
-        T* T1T = tmp.getz<T>((size_t)ev(r2) * j.rows, s);
+        T* T1T = lru.M ? tmp.getz<T>((size_t)ev(r2) * j.rows, s) : CgT;
         pieces.push_back(SubJob<T>{lru.C, lru.ldc, j.ri, nullptr, j.r0, 0, j.rows, r1, CgT, ev(r1), 1});
         pieces.push_back(SubJob<T>{lru.Z, lru.ldz, nullptr, j.ci, 0, j.c0, r2, j.cols, ZgT, ev(j.cols), 1});
-        g1.push_back(GemmProb<T>{MT, CgT, T1T, r2, j.rows, r1, ev(r2), ev(r1), ev(r2)});
+        if (lru.M) g1.push_back(GemmProb<T>{MT, CgT, T1T, r2, j.rows, r1, ev(r2), ev(r1), ev(r2)});
         g2.push_back(GemmProb<T>{ZgT, T1T, j.out, j.cols, j.rows, r2, ev(j.cols), ev(r2), j.ldo});
       }
     }
@@ -1039,20 +1039,18 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
   }
   if (lru.on()) {  // Ys -= C*(M*(Z*OPs)),  W -= ((PsT*C)*M)*Z
     const int r1 = lru.r1, r2 = lru.r2;
-    T* t1 = tmp.get<T>((size_t)ev(r2) * k);
-    T* t2 = tmp.get<T>((size_t)ev(r1) * k);
-    T* u1 = tmp.get<T>((size_t)ldk * r1);
-    T* u2 = tmp.get<T>((size_t)ldk * r2);
-    HSS_HIP(hipMemsetAsync(t1, 0, sizeof(T) * (size_t)ev(r2) * k, s));
-    HSS_HIP(hipMemsetAsync(t2, 0, sizeof(T) * (size_t)ev(r1) * k, s));
-    HSS_HIP(hipMemsetAsync(u1, 0, sizeof(T) * (size_t)ldk * r1, s));
-    HSS_HIP(hipMemsetAsync(u2, 0, sizeof(T) * (size_t)ldk * r2, s));
+    T* t1 = tmp.getz<T>((size_t)ev(r2) * k, s);
+    T* u1 = tmp.getz<T>((size_t)ldk * r1, s);
+    T* t2 = lru.M ? tmp.getz<T>((size_t)ev(r1) * k, s) : t1;  // M == nullptr: the identity (r1 == r2)
+    T* u2 = lru.M ? tmp.getz<T>((size_t)ldk * r2, s) : u1;
     gemms.push_back(GemmProb<T>{lru.Z, OPs, t1, r2, k, n, lru.ldz, ldn, ev(r2)});
     gemms.push_back(GemmProb<T>{PsT, lru.C, u1, k, r1, n, ldk, lru.ldc, ldk});
     run_gemms(tmp, gemms, 0, s);
-    gemms.push_back(GemmProb<T>{lru.M, t1, t2, r1, k, r2, lru.ldm, ev(r2), ev(r1)});
-    gemms.push_back(GemmProb<T>{u1, lru.M, u2, k, r2, r1, ldk, lru.ldm, ldk});
-    run_gemms(tmp, gemms, 0, s);
+    if (lru.M) {
+      gemms.push_back(GemmProb<T>{lru.M, t1, t2, r1, k, r2, lru.ldm, ev(r2), ev(r1)});
+      gemms.push_back(GemmProb<T>{u1, lru.M, u2, k, r2, r1, ldk, lru.ldm, ldk});
+      run_gemms(tmp, gemms, 0, s);
+    }
     gemms.push_back(GemmProb<T>{lru.C, t2, Ys, n, k, r1, lru.ldc, ev(r1), ldn});
     gemms.push_back(GemmProb<T>{u2, lru.Z, W, k, n, r2, ldk, lru.ldz, ldk});
     run_gemms(tmp, gemms, 1, s);
@@ -1936,7 +1934,8 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
   }
   Lru<T> lru;
   if (la && la->r1 > 0 && la->r2 > 0) {
-    if (!la->C || !la->M || !la->Z || la->ldc < n || la->ldm < la->r1 || la->ldz < la->r2 || la->r1 > n || la->r2 > n) {
+    const bool m_id = !la->M && where != 0 && la->r1 == la->r2;  // device operands: M == NULL stands for the identity
+    if (!la->C || (!la->M && !m_id) || !la->Z || la->ldc < n || (la->M && la->ldm < la->r1) || la->ldz < la->r2 || la->r1 > n || la->r2 > n) {
       hs_set_error(HS_ERR_DIMENSION, 0, "DimensionMismatch: the low-rank update needs C (n x r1), M (r1 x r2), Z (r2 x n)");
       throw (int)HS_ERR_DIMENSION;
     }

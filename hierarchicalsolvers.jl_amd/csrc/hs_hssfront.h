@@ -140,6 +140,19 @@ static void free_hss_nodes(hs_handle* h) {
       (void)hipFree(x.hW);
       x.hW = nullptr;
     }
+    if (x.hss2) {
+      hs_hss_free((hs_hss*)x.hss2);
+      x.hss2 = nullptr;
+    }
+    if (x.hss_keep) {
+      hs_hss_free((hs_hss*)x.hss_keep);
+      x.hss_keep = nullptr;
+    }
+    for (void** q : {&x.bW12, &x.bZ12, &x.bC21, &x.bZ21})
+      if (*q) {
+        (void)hipFree(*q);
+        *q = nullptr;
+      }
   }
 }
 static void free_hss_any(hs_handle* h) {
@@ -299,6 +312,66 @@ static void factor_hss_fronts(hs_handle* h, const int* ids, int count, const Nod
   cleanup();
 }
 
+// B (ni x q, device) <- D^-1 B for a front whose interior block is held in HSS form: one HSS solve, or the reference's block solve
+// `blockldiv!` (src/blockmatrix.jl:134-144) over [A11 A12; A21 A22] with S22 = A22 - A21*A11^-1*A12:
+//   y1 = A11^-1 B1;  x2 = S22^-1 (B2 - A21 y1);  x1 = y1 - (A11^-1 A12) x2          (A12 = C12*Z12, A21 = C21*Z21, W12 = A11^-1*C12)
+template <class T>
+static void hss_d_solve(hs_handle* h, const NodeH& x, T* B, int ldb, int q, hipStream_t s) {
+  auto hsolve = [&](void* H, T* b) {
+    int st = hs_hss_set_stream((hs_hss*)H, (void*)s);
+    if (st == 0) st = hs_hss_ldiv((hs_hss*)H, (double*)b, ldb, q, 1);
+    if (st != 0) throw HsError{st};
+  };
+  if (!x.mfb) {
+    hsolve(x.hss, B);
+    return;
+  }
+  const int n1 = x.ni1, n2 = x.ni - x.ni1, k12 = x.bk12, k21 = x.bk21;
+  T *B1 = B, *B2 = B + n1;
+  hsolve(x.hss, B1);
+  if (q == 1) {
+    if (k21 > 0) {
+      ensure_lr_workspace<T>(h, k21, n1);
+      launch_lr_zmul<T>((const T*)x.bZ21, x.bldz21, k21, n1, B1, nullptr, (T*)h->d_lr_part, (T*)h->d_lr_t, s);
+      launch_lr_dense<T>((const T*)x.bC21, x.bldc21, n2, k21, (const T*)h->d_lr_t, B2, nullptr, s);
+    }
+    hsolve(x.hss2, B2);
+    if (k12 > 0) {
+      ensure_lr_workspace<T>(h, k12, n2);
+      launch_lr_zmul<T>((const T*)x.bZ12, x.bldz12, k12, n2, B2, nullptr, (T*)h->d_lr_part, (T*)h->d_lr_t, s);
+      launch_lr_dense<T>((const T*)x.bW12, x.bldw, n1, k12, (const T*)h->d_lr_t, B1, nullptr, s);
+    }
+    return;
+  }
+  // blocks of right-hand sides (W = D^-1 C_R during the factorization): the same steps as MFMA products
+  const int kmax = std::max(std::max(k12, k21), 1), ldt = (kmax + 1) / 2 * 2;
+  T* t = nullptr;
+  GemmProb<T>* dgp = nullptr;
+  dmalloc((void**)&t, ((size_t)ldt * q + 32) * sizeof(T), "block-solve scratch");
+  dmalloc((void**)&dgp, 2 * sizeof(GemmProb<T>), "GEMM descriptors");
+  auto pair = [&](const T* Z, int ldz, int k, int cols, const T* X, const T* C, int ldc, int rows, T* Y) {  // Y -= C * (Z * X)
+    if (k <= 0) return;
+    GemmProb<T> gp[2] = {GemmProb<T>{Z, X, t, k, q, cols, ldz, ldb, ldt}, GemmProb<T>{C, t, Y, rows, q, k, ldc, ldt, ldb}};
+    HS_HIP(hipMemcpyAsync(dgp, gp, sizeof gp, hipMemcpyHostToDevice, s));
+    HS_HIP(hipStreamSynchronize(s));
+    launch_gemm_probs<T>(dgp, 1, k, q, 0, s);
+    launch_gemm_probs<T>(dgp + 1, 1, rows, q, 1, s);
+  };
+  try {
+    pair((const T*)x.bZ21, x.bldz21, k21, n1, B1, (const T*)x.bC21, x.bldc21, n2, B2);
+    hsolve(x.hss2, B2);
+    pair((const T*)x.bZ12, x.bldz12, k12, n2, B2, (const T*)x.bW12, x.bldw, n1, B1);
+    HS_HIP(hipStreamSynchronize(s));
+  } catch (...) {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(t);
+    (void)hipFree(dgp);
+    throw;
+  }
+  (void)hipFree(t);
+  (void)hipFree(dgp);
+}
+
 // forward sweep of level lv:  t = H^-1 rhs[int];  rhs[bnd] -= C_L * (Z_L * t)
 template <class T>
 static void solve_hss_fwd(hs_handle* h, int lv, T* db, hipStream_t s) {
@@ -308,9 +381,7 @@ static void solve_hss_fwd(hs_handle* h, int lv, T* db, hipStream_t s) {
     if (!(x.hssd || x.mf) || !x.hss) continue;
     T* t = (T*)x.ht;
     launch_pack_idx(h->d_int + x.off_fidx, x.ni, db, t, (int)sizeof(T), s);
-    int st = hs_hss_set_stream((hs_hss*)x.hss, (void*)s);
-    if (st == 0) st = hs_hss_ldiv((hs_hss*)x.hss, (double*)t, x.ni, 1, 1);
-    if (st != 0) throw HsError{st};
+    hss_d_solve<T>(h, x, t, x.ni, 1, s);
     if (x.nb == 0 || !x.lrL) continue;
     const LowRank<T>& lr = *(const LowRank<T>*)x.lrL;
     if (lr.r == 0) continue;

@@ -87,6 +87,12 @@ static void mf_couplings(hs_handle* h, int64_t n, const int64_t* colptr, const i
           x.xr.row.push_back(p); x.xr.col.push_back(c - x.ni); x.xr.e.push_back(e);
         } else if (p >= x.ni && c < x.ni) {
           x.xl.row.push_back(p - x.ni); x.xl.col.push_back(c); x.xl.e.push_back(e);
+        } else if (x.mfb && p < x.ni && c < x.ni) {  // A[int1, int2] / A[int2, int1] of the 2x2 block form of D
+          if (p < x.ni1) {
+            x.x12.row.push_back(p); x.x12.col.push_back(c - x.ni1); x.x12.e.push_back(e);
+          } else {
+            x.x21.row.push_back(p - x.ni1); x.x21.col.push_back(c); x.x21.e.push_back(e);
+          }
         }
       }
     }
@@ -466,7 +472,8 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
       HS_HIP(hipMemcpyAsync(dslot, &d, sizeof d, hipMemcpyHostToDevice, s));
       HS_HIP(hipMemcpyAsync(sslot, &q, sizeof q, hipMemcpyHostToDevice, s));
       HS_HIP(hipStreamSynchronize(s));  // d, q are stack objects
-      const int cb = 1024, ldi = rup(x.ni, 2);
+      static const int cb_env = getenv("HS_MF_EXPAND_COLS") ? atoi(getenv("HS_MF_EXPAND_COLS")) : 4096;
+      const int cb = std::max(256, cb_env), ldi = rup(x.ni, 2);  // columns of the identity per application of the operator
       T* I_ = buf.get((size_t)ldi * cb, "identity block");
       const bool lone = (s == h->stream);  // the look-ahead streams belong to the handle: only a front that runs alone may use them
       Profiler prof;                       // h->prof is not shared between concurrent fronts
@@ -516,6 +523,90 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
         lrR->ldc = ldu;
       }
     } else {
+      const bool blockD = x.mfb && ch1.n1 > 0 && ch2.n1 > 0 && ch1.a11 && ch2.a11;
+      x.mfb = blockD;
+      if (blockD) {
+        // ---- D = blockfactor([A11 A12; A21 A22]) over HSS blocks (src/blockmatrix.jl:121-130): A11 = S1.A11 is the left child's own HSS block
+        // (nothing is compressed again), A12 / A21 are the sparse couplings factored exactly by their nonzero rows / columns, and the Schur
+        // complement S22 = A22 - A21*A11^-1*A12 = S2.A11 - C21*(Z21*A11^-1*C12)*Z12 is RECOMPRESSED from that operator (the role of `recompress!`)
+        const int n1 = ch1.n1, n2 = ch2.n1;
+        std::vector<HsFillEntry> fc12, fz12, fc21, fz21;
+        const int k12 = mf_factor_coupling(x.x12, 0, fc12, fz12), k21 = mf_factor_coupling(x.x21, 0, fc21, fz21);
+        x.bk12 = k12; x.bk21 = k21;
+        x.bldw = rup(n1, 2); x.bldz12 = rup(std::max(k12, 1), 2); x.bldc21 = rup(n2, 2); x.bldz21 = rup(std::max(k21, 1), 2);
+        T *W12 = nullptr, *Z12 = nullptr, *C21 = nullptr, *Z21 = nullptr;
+        zalloc(&W12, (size_t)x.bldw * std::max(k12, 1), "A11^-1*C12");
+        x.bW12 = W12;
+        zalloc(&Z12, (size_t)x.bldz12 * n2, "Z12");
+        x.bZ12 = Z12;
+        zalloc(&C21, (size_t)x.bldc21 * std::max(k21, 1), "C21");
+        x.bC21 = C21;
+        zalloc(&Z21, (size_t)x.bldz21 * n1, "Z21");
+        x.bZ21 = Z21;
+        mf_fill<T>(h, fc12, W12, x.bldw, buf, s);
+        mf_fill<T>(h, fz12, Z12, x.bldz12, buf, s);
+        mf_fill<T>(h, fc21, C21, x.bldc21, buf, s);
+        mf_fill<T>(h, fz21, Z21, x.bldz21, buf, s);
+        x.hss = ch1.a11;  // the view now belongs to this front; the matrix it shares its generators with stays alive with it
+        ch1.a11 = nullptr;
+        if (!h->opts.keep_schur) {
+          x.hss_keep = c1.S_hss;
+          c1.S_hss = nullptr;
+        }
+        mf_check(hs_hss_set_stream((hs_hss*)x.hss, (void*)s));
+        int st = hs_hss_factor((hs_hss*)x.hss);
+        if (st == 0 && k12 > 0) st = hs_hss_ldiv((hs_hss*)x.hss, (double*)W12, x.bldw, k12, 1);
+        if (st != 0) {
+          if (st == HS_ERR_SINGULAR) hs_set_error(HS_ERR_SINGULAR, id, "SingularException: the block A11 of the interior block of node %d is singular", id);
+          throw HsError{st};
+        }
+        lap("D: A11 eliminated, A11^-1 A12");
+        T* M22 = nullptr;
+        int ldm22 = 2;
+        if (k12 > 0 && k21 > 0) {  // Z21 * (A11^-1 C12)
+          ldm22 = rup(k21, 2);
+          M22 = buf.get((size_t)ldm22 * k12, "Z21*A11^-1*C12");
+          HS_HIP(hipMemsetAsync(M22, 0, sizeof(T) * (size_t)ldm22 * k12, s));
+          GemmProb<T> gp{Z21, W12, M22, k21, k12, n1, x.bldz21, x.bldw, ldm22};
+          GemmProb<T>* dgp = (GemmProb<T>*)buf.get((sizeof(GemmProb<T>) + sizeof(T) - 1) / sizeof(T), "GEMM descriptor");
+          HS_HIP(hipMemcpyAsync(dgp, &gp, sizeof gp, hipMemcpyHostToDevice, s));
+          HS_HIP(hipStreamSynchronize(s));
+          launch_gemm_probs<T>(dgp, 1, k21, k12, 0, s);
+        }
+        // the couplings of a two-layer separator have FULL rank (k12 = k21 = ni/2): the update is folded into two factors, C21 * (M22*Z12),
+        // so that the compression corrects a block of entries with one product instead of two through a 16,384 x 16,384 middle factor
+        T* MZ = nullptr;
+        if (k12 > 0 && k21 > 0) {
+          MZ = buf.get((size_t)ldm22 * n2, "Z21*A11^-1*A12");
+          HS_HIP(hipMemsetAsync(MZ, 0, sizeof(T) * (size_t)ldm22 * n2, s));
+          GemmProb<T> gp{M22, Z12, MZ, k21, n2, k12, ldm22, x.bldz12, ldm22};
+          GemmProb<T>* dgp = (GemmProb<T>*)buf.get((sizeof(GemmProb<T>) + sizeof(T) - 1) / sizeof(T), "GEMM descriptor");
+          HS_HIP(hipMemcpyAsync(dgp, &gp, sizeof gp, hipMemcpyHostToDevice, s));
+          HS_HIP(hipStreamSynchronize(s));
+          launch_gemm_probs<T>(dgp, 1, k21, n2, 0, s);
+        }
+        hs_hss_blockop op22{n2, 0, ch2.a11, nullptr, gid.data() + n1, &As, (int32_t*)h->d_lpos};
+        hs_hss_options o = mf_options(h, id, dsc, 0, x.last_k, n2);
+        hs_hss* S22 = nullptr;
+        const bool u22 = k12 > 0 && k21 > 0;
+        mf_check(h->is_complex ? hs_hss_compress_blockop_z(&op22, (const double*)C21, x.bldc21, nullptr, 0, (const double*)MZ, ldm22, u22 ? k21 : 0, u22 ? k21 : 0, nullptr, &o, s, &S22)
+                               : hs_hss_compress_blockop_d(&op22, (const double*)C21, x.bldc21, nullptr, 0, (const double*)MZ, ldm22, u22 ? k21 : 0, u22 ? k21 : 0, nullptr, &o, s, &S22));
+        x.hss2 = S22;
+        lap("D: S22 = A22 - A21 A11^-1 A12 recompressed");
+        st = hs_hss_factor(S22);
+        if (st != 0) {
+          if (st == HS_ERR_SINGULAR) hs_set_error(HS_ERR_SINGULAR, id, "SingularException: the Schur complement S22 of the interior block of node %d is singular", id);
+          throw HsError{st};
+        }
+        lap("D: S22 eliminated");
+        x.last_k = (int)hs_hss_samples(S22);
+        const long long rD = std::max<long long>(hs_hss_rank((hs_hss*)x.hss), hs_hss_rank(S22));
+        mf_maxrank(h, rD);
+        if (say)
+          fprintf(stderr, "[hs] node %d (level %d, ni=%d, nb=%d): blockfactor(D): hssrank(A11)=%lld, couplings of rank %d / %d, hssrank(S22)=%lld (%lld samples)\n", id, x.level,
+                  x.ni, x.nb, (long long)hs_hss_rank((hs_hss*)x.hss), k12, k21, (long long)hs_hss_rank(S22), (long long)hs_hss_samples(S22));
+        if (!x.ht) dmalloc(&x.ht, ((size_t)x.ni + 32) * sizeof(T), "HSS solve vector");
+      } else
       // ---- D = Aii as one HSS matrix, compressed from the operator [S1.A11 A[int1,int2]; A[int2,int1] S2.A11] ------------------------------
       {
         hs_hss_options o = mf_options(h, id, dsc, 0, x.last_k, x.ni);
@@ -545,8 +636,7 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
         lap("Aib, Abi from the generators");
         // ---- W = Aii^-1 * C_R (the R transform; C_R itself is not needed again) -------------------------------------------------------------------
         if (rR > 0) {
-          mf_check(hs_hss_set_stream((hs_hss*)x.hss, (void*)s));
-          mf_check(hs_hss_ldiv((hs_hss*)x.hss, (double*)lrR->Cd, lrR->ldc, rR, 1));
+          hss_d_solve<T>(h, x, lrR->Cd, lrR->ldc, rR, s);
           x.hW = lrR->Cd;  // ownership moves to the node (freed with the HSS objects); the low-rank object keeps only Z_R
           x.hldw = lrR->ldc;
           lrR->Cd = nullptr;

@@ -86,8 +86,10 @@ class SolverOptions:
             o.mf = 1  # interior blocks of the matrix-free fronts dense unless hss_min asks for HSS
         elif self.mf in (2, "hss"):
             o.mf = 2  # every interior block an HSS matrix (the reference's formulation)
+        elif self.mf in (3, "block"):
+            o.mf = 3  # interior blocks as the reference's 2x2 block factorization over the children's HSS blocks (blockmatrix.jl:121-130)
         else:
-            raise ValueError("mf must be False, True / 'dense' or 2 / 'hss'")
+            raise ValueError("mf must be False, True / 'dense', 2 / 'hss' or 3 / 'block'")
         if self.hss_dexp is not None:
             if not 0 <= int(self.hss_dexp) <= 12:
                 raise ValueError("hss_dexp must be in 0:12")

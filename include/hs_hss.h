@@ -123,7 +123,8 @@ typedef struct hs_hss_blockop {
   const hs_sparse_dev* A;
   int32_t* lpos;       /* DEVICE scratch of A->n ints, all -1 on entry; restored to -1 on return */
 } hs_hss_blockop;
-/* H ~= (Op - C*M*Z)[perm, perm] (C, M, Z on the device; r1 = 0 or r2 = 0: no update; perm on the host or NULL) */
+/* H ~= (Op - C*M*Z)[perm, perm] (C, M, Z on the device; r1 = 0 or r2 = 0: no update; M = NULL with r1 = r2: M is the identity;
+   perm on the host or NULL) */
 int hs_hss_compress_blockop_d(const hs_hss_blockop* op, const double* C, int64_t ldc, const double* M, int64_t ldm, const double* Z, int64_t ldz,
                               int64_t r1, int64_t r2, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
 int hs_hss_compress_blockop_z(const hs_hss_blockop* op, const double* C, int64_t ldc, const double* M, int64_t ldm, const double* Z, int64_t ldz,

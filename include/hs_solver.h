@@ -72,7 +72,10 @@ typedef struct hs_options {
                          flagged front leaves as an HSS matrix compressed from the operator Abb - Abi*R (never formed where the children are HSS),
                          a parent with two such children is assembled matrix-free from their generators and the sparse couplings of A: Aib, Abi
                          and Abb are never dense, L / R come from the children's generators (hs_mffront.h).
-                         2: D = Aii of such a parent is ONE HSS matrix compressed from its operator, like the reference's (hss_dexp sets its tolerance).
+                         3: D = Aii of such a parent is the reference's `blockfactor` over HSS blocks (src/blockmatrix.jl:121-130): A11 is the left
+                            child's own HSS block, A12 / A21 the sparse couplings, S22 = A22 - A21*A11^-1*A12 recompressed from its operator
+                            (hss_dexp sets its tolerance); `ldiv!` runs `blockldiv!` (two HSS solves).
+                         2: D is ONE HSS matrix over a bisection order of the interior, compressed from the operator [A11 A12; A21 A22].
                          1: D is expanded from the generators and eliminated densely by the front kernels (ni x ni, the one dense block of the
                             front), except on the fronts hss_d selects: the dense LU of a 32,768 block takes 0.5 s, its HSS compression +
                             elimination at 1e-4 1.8 s.

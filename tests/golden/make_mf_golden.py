@@ -1,5 +1,5 @@
 """Generate tests/golden/mf_oracle.json: what the CPU restatement of the matrix-free compressed branch (oracle/hs_oracle_mf.py,
-`dmode="single"`) produces on the cases of tests/test_mf_gpu.py -- solution error against SuperLU, maxrank, and per matrix-free front the
+`dmode="single"` and `dmode="block"`) produces on the cases of tests/test_mf_gpu.py -- solution error against SuperLU, maxrank, and per matrix-free front the
 HSS rank of D, rank(L), rank(R) and the HSS rank of S.  DATA ONLY; the oracle takes about a minute per case, too long for the GPU suite.
 
     python tests/golden/make_mf_golden.py
@@ -46,13 +46,15 @@ def main():
         P = prepare(hs, name[0], rhs="randn", **name[1])
         xr = spla.splu(P["A"]).solve(P["b"])
         for tol in TOLS:
-            F = OM.factor(P["A"], P["ond"], P["ond_loc"], dexp=2, dmode="single", swlevel=swlevel, swsize=8, atol=tol, rtol=tol, leafsize=128)
-            nodes = []
-            walk(F, nodes)
-            key = f"{cname}/tol={tol:g}"
-            res[key] = dict(err_vs_splu=float(relerr(OM.ldiv(F, P["b"]), xr)), maxrank=int(OM.maxrank(F)), fronts=nodes,
-                            options=dict(swlevel=swlevel, swsize=8, atol=tol, rtol=tol, leafsize=128, dexp=2, dmode="single"))
-            print(key, res[key]["err_vs_splu"], res[key]["maxrank"], flush=True)
+            # "single": D of a matrix-free front as one HSS matrix (hs_options.mf = 2); "block": the reference's 2x2 blockfactor (mf = 3)
+            for dmode, suffix in (("single", ""), ("block", "/block")):
+                F = OM.factor(P["A"], P["ond"], P["ond_loc"], dexp=2, dmode=dmode, swlevel=swlevel, swsize=8, atol=tol, rtol=tol, leafsize=128)
+                nodes = []
+                walk(F, nodes)
+                key = f"{cname}/tol={tol:g}{suffix}"
+                res[key] = dict(err_vs_splu=float(relerr(OM.ldiv(F, P["b"]), xr)), maxrank=int(OM.maxrank(F)), fronts=nodes,
+                                options=dict(swlevel=swlevel, swsize=8, atol=tol, rtol=tol, leafsize=128, dexp=2, dmode=dmode))
+                print(key, res[key]["err_vs_splu"], res[key]["maxrank"], flush=True)
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mf_oracle.json"), "w") as f:
         json.dump(res, f, indent=1)
 
