@@ -172,13 +172,13 @@ static void mf_check(int st) {
 }
 
 // The compressions of the fronts of one level are independent chains of small dependent launches (tree levels x windows of rows): run
-// alone, each leaves most of the chip idle.  Up to HS_MF_THREADS (default 4) of them run concurrently, one host thread and one HIP stream
+// alone, each leaves most of the chip idle.  Up to HS_MF_THREADS (default 2: the chains are bound by the host side of the launches, which does not scale over threads) of them run concurrently, one host thread and one HIP stream
 // each (the HSS module is synchronous per call; its block caches are mutex-guarded, its error state thread-local).  body(i, stream) may
 // throw HsError / int; the first failure is re-raised on the calling thread with its message.
 static std::mutex g_mf_mu;  // guards hs_handle::maxrank and verbose output ordering
 template <class F>
 static void mf_parallel(hs_handle* h, int count, F&& body) {
-  static const int nth_env = getenv("HS_MF_THREADS") ? atoi(getenv("HS_MF_THREADS")) : 4;
+  static const int nth_env = getenv("HS_MF_THREADS") ? atoi(getenv("HS_MF_THREADS")) : 2;  // measured at Poisson 128^3, mf = 1: 4.32 / 3.88 / 3.98 / 4.03 / 4.51 s with 1 / 2 / 3 / 4 / 8 threads
   const int nth = std::max(1, std::min(count, nth_env));
   HS_HIP(hipStreamSynchronize(h->stream));  // everything the fronts read has been produced
   if (nth == 1) {
