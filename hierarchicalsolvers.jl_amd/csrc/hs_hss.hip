@@ -1526,23 +1526,20 @@ void hss_getindex(HssT<T>& H, const int64_t* I, int ni, const int64_t* J, int nj
 // `U*B12`, `V` factors a parent front builds its low-rank couplings from (src/factorization.jl:129-137).  Bottom-up over the subtree:
 // leaf U = P^T [I; T]; inner node U = blkdiag(U_left, U_right) * P^T [I; T].
 // ------------------------------------------------------------------------------------------------
+// expanded bases E[i] (rows of node i x r_i) of every node of the subtree under `node` (node == 0: of every node but the root), level by
+// level from the leaves with one group of launches per level; the basis of `node` itself is written to out when node > 0
 template <class T>
-void hss_basis(HssT<T>& H, int node, T* out, int ldo) {
+static void hss_bases_impl(HssT<T>& H, Pool& tmp, int node, T* out, int ldo, std::vector<T*>& E, std::vector<int>& lde) {
   hipStream_t s = H.s;
   auto& nd = H.nd;
   const int N = (int)nd.size();
-  if (node <= 0 || node >= N) {
-    hs_set_error(HS_ERR_ARGUMENT, node, "ArgumentError: HSS node %d has no basis (the root has none)", node);
-    throw (int)HS_ERR_ARGUMENT;
-  }
-  Pool tmp(global_cache());
   // the subtree, by level
   std::vector<std::vector<int>> lv(H.nlev);
   std::vector<int> cur{node};
   while (!cur.empty()) {
     std::vector<int> nxt;
     for (int i : cur) {
-      lv[nd[i].level].push_back(i);
+      if (i != 0) lv[nd[i].level].push_back(i);
       if (nd[i].left >= 0) {
         nxt.push_back(nd[i].left);
         nxt.push_back(nd[i].right);
@@ -1550,18 +1547,18 @@ void hss_basis(HssT<T>& H, int node, T* out, int ldo) {
     }
     cur.swap(nxt);
   }
-  std::vector<T*> E(N, nullptr);
-  std::vector<int> lde(N, 0);
+  E.assign(N, nullptr);
+  lde.assign(N, 0);
   auto target = [&](int i) {  // the requested node writes straight into `out`
-    if (i == node) {
+    if (i == node && node > 0) {
       E[i] = out;
       lde[i] = ldo;
     } else {
       lde[i] = ev(nd[i].hi - nd[i].lo);
-      E[i] = tmp.get<T>((size_t)lde[i] * nd[i].r);
+      E[i] = tmp.get<T>((size_t)lde[i] * std::max(nd[i].r, 1));
     }
   };
-  for (int l = H.nlev - 1; l >= nd[node].level; --l) {
+  for (int l = H.nlev - 1; l >= std::max(nd[node].level, 1); --l) {
     std::vector<BasisJob<T>> bj;
     std::vector<SubJob<T>> blocks, cg;
     std::vector<RowJob<T>> neg;
@@ -1609,6 +1606,70 @@ void hss_basis(HssT<T>& H, int node, T* out, int ldo) {
     run_subs(tmp, cg, s);
     run_gemms(tmp, ge, 1, s);
   }
+}
+template <class T>
+void hss_basis(HssT<T>& H, int node, T* out, int ldo) {
+  const int N = (int)H.nd.size();
+  if (node <= 0 || node >= N) {
+    hs_set_error(HS_ERR_ARGUMENT, node, "ArgumentError: HSS node %d has no basis (the root has none)", node);
+    throw (int)HS_ERR_ARGUMENT;
+  }
+  Pool tmp(global_cache());
+  std::vector<T*> E;
+  std::vector<int> lde;
+  hss_bases_impl<T>(H, tmp, node, out, ldo, E, lde);
+  HSS_HIP(hipStreamSynchronize(H.s));
+}
+
+// `Matrix(H)` / `full(H)` of HssMatrices.jl: out (n x n, device) = the matrix H represents, in H's own index order (for a compressed matrix
+// A[perm, perm]; the block views of hs_hss_child carry no permutation).  Every node's expanded basis once (O(n r^2) per level), then per
+// inner node the two products U_l*B12*U_r^T and U_r*B21*U_l^T written into their place and the leaves' D blocks copied: 2 n^2 r flops,
+// a tenth of applying H to the identity.
+template <class T>
+void hss_expand(HssT<T>& H, T* out, int ldo) {
+  hipStream_t s = H.s;
+  auto& nd = H.nd;
+  const int N = (int)nd.size();
+  Pool tmp(global_cache());
+  HSS_HIP(hipMemset2DAsync(out, sizeof(T) * ldo, 0, sizeof(T) * H.n, H.n, s));
+  std::vector<SubJob<T>> copies, tr;
+  std::vector<GemmProb<T>> g1, g2;
+  if (nd[0].left < 0) {
+    copies.push_back(SubJob<T>{nd[0].D, nd[0].ldd, nullptr, nullptr, 0, 0, H.n, H.n, out, ldo, 0});
+    run_subs(tmp, copies, s);
+    HSS_HIP(hipStreamSynchronize(s));
+    return;
+  }
+  std::vector<T*> E;
+  std::vector<int> lde;
+  hss_bases_impl<T>(H, tmp, 0, nullptr, 0, E, lde);
+  std::vector<T*> ET(N, nullptr);  // E_i^T (r_i x rows): the right factor of a sibling's block
+  for (int i = 1; i < N; ++i) {
+    const int cnt = nd[i].hi - nd[i].lo, r = nd[i].r;
+    if (r <= 0) continue;
+    ET[i] = tmp.get<T>((size_t)ev(r) * cnt);
+    tr.push_back(SubJob<T>{E[i], lde[i], nullptr, nullptr, 0, 0, cnt, r, ET[i], ev(r), 1});
+  }
+  run_subs(tmp, tr, s);
+  for (int i = 0; i < N; ++i) {
+    const HNode<T>& x = nd[i];
+    if (x.left < 0) {
+      copies.push_back(SubJob<T>{x.D, x.ldd, nullptr, nullptr, 0, 0, x.m, x.m, out + x.lo + (size_t)x.lo * ldo, ldo, 0});
+      continue;
+    }
+    const HNode<T>&l = nd[x.left], &r = nd[x.right];
+    const int cl = l.hi - l.lo, cr = r.hi - r.lo, rl = l.r, rr = r.r;
+    if (rl <= 0 || rr <= 0) continue;
+    T* t12 = tmp.getz<T>((size_t)ev(cl) * rr, s);
+    T* t21 = tmp.getz<T>((size_t)ev(cr) * rl, s);
+    g1.push_back(GemmProb<T>{E[x.left], x.B12, t12, cl, rr, rl, lde[x.left], x.ld12, ev(cl)});
+    g1.push_back(GemmProb<T>{E[x.right], x.B21, t21, cr, rl, rr, lde[x.right], x.ld21, ev(cr)});
+    g2.push_back(GemmProb<T>{t12, ET[x.right], out + l.lo + (size_t)r.lo * ldo, cl, cr, rr, ev(cl), ev(rr), ldo});
+    g2.push_back(GemmProb<T>{t21, ET[x.left], out + r.lo + (size_t)l.lo * ldo, cr, cl, rl, ev(cr), ev(rl), ldo});
+  }
+  run_subs(tmp, copies, s);
+  run_gemms(tmp, g1, 0, s);
+  run_gemms(tmp, g2, 0, s);
   HSS_HIP(hipStreamSynchronize(s));
 }
 
@@ -2546,6 +2607,30 @@ static void offdiag_impl(HssT<T>& H, int which, T* C_, int ldc, T* Z, int ldz) {
   run_subs(tmp, t, s);
   HSS_HIP(hipStreamSynchronize(s));
 }
+extern "C" int hs_hss_expand(hs_hss* H, double* out, int64_t ldo, int where) {
+  if (!H || !out || ldo < hs_hss_size(H)) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_expand needs an n x n result (ldo >= n)");
+    return HS_ERR_ARGUMENT;
+  }
+  HSS_GUARD(
+      if (where != 0) {
+        if (H->is_complex) hss_expand<cplx>(*HZ(H), (cplx*)out, (int)ldo);
+        else hss_expand<double>(*HD(H), out, (int)ldo);
+      } else {
+        Pool st(global_cache());
+        const int n = (int)hs_hss_size(H), ld = ev(n);
+        if (H->is_complex) {
+          cplx* d = st.get<cplx>((size_t)ld * n);
+          hss_expand<cplx>(*HZ(H), d, ld);
+          HSS_HIP(hipMemcpy2D(out, sizeof(cplx) * ldo, d, sizeof(cplx) * ld, sizeof(cplx) * n, n, hipMemcpyDeviceToHost));
+        } else {
+          double* d = st.get<double>((size_t)ld * n);
+          hss_expand<double>(*HD(H), d, ld);
+          HSS_HIP(hipMemcpy2D(out, sizeof(double) * ldo, d, sizeof(double) * ld, sizeof(double) * n, n, hipMemcpyDeviceToHost));
+        }
+      });
+}
+
 extern "C" int hs_hss_offdiag(hs_hss* H, int which, double* C_, int64_t ldc, double* Z, int64_t ldz, int where) {
   if (!H || !C_ || !Z || (which != 0 && which != 1)) {
     hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_offdiag needs which in {0, 1} and two output blocks");

@@ -87,7 +87,7 @@ static void mf_couplings(hs_handle* h, int64_t n, const int64_t* colptr, const i
           x.xr.row.push_back(p); x.xr.col.push_back(c - x.ni); x.xr.e.push_back(e);
         } else if (p >= x.ni && c < x.ni) {
           x.xl.row.push_back(p - x.ni); x.xl.col.push_back(c); x.xl.e.push_back(e);
-        } else if (x.mfb && p < x.ni && c < x.ni) {  // A[int1, int2] / A[int2, int1] of the 2x2 block form of D
+        } else if ((x.mfb || x.mfd) && p < x.ni && c < x.ni) {  // A[int1, int2] / A[int2, int1]: the 2x2 block form of D, the dense expansion
           if (p < x.ni1) {
             x.x12.row.push_back(p); x.x12.col.push_back(c - x.ni1); x.x12.e.push_back(e);
           } else {
@@ -474,17 +474,37 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
       HS_HIP(hipStreamSynchronize(s));  // d, q are stack objects
       static const int cb_env = getenv("HS_MF_EXPAND_COLS") ? atoi(getenv("HS_MF_EXPAND_COLS")) : 4096;
       const int cb = std::max(256, cb_env), ldi = rup(x.ni, 2);  // columns of the identity per application of the operator
-      T* I_ = buf.get((size_t)ldi * cb, "identity block");
+      T* I_ = nullptr;
+      std::vector<HsFillEntry> f12, f21;
       const bool lone = (s == h->stream);  // the look-ahead streams belong to the handle: only a front that runs alone may use them
       Profiler prof;                       // h->prof is not shared between concurrent fronts
       for (int attempt = 0; attempt < 2; ++attempt) {
         HS_HIP(hipMemsetAsync(LF, 0, ((size_t)ldl * x.ni + 32) * sizeof(T), s));
         HS_HIP(hipMemsetAsync(UR, 0, ((size_t)ldu * nbp + 32) * sizeof(T), s));
         HS_HIP(hipMemsetAsync(SB, 0, ((size_t)ldsb * nbp + 32) * sizeof(T), s));
-        for (int c0 = 0; c0 < x.ni; c0 += cb) {
-          const int nc = std::min(cb, x.ni - c0);
-          launch_identity_cols<T>(I_, ldi, x.ni, c0, nc, s);
-          mf_check(hs_hss_blockop_apply(&opd, h->is_complex, (const double*)I_, ldi, (double*)(LF + (size_t)c0 * ldl), ldl, nc, 0, s));
+        static const bool by_apply = getenv("HS_MF_EXPAND_APPLY") != nullptr;  // diagnostics: expand D by applying the operator to the identity
+        if (by_apply) {
+          if (!I_) I_ = buf.get((size_t)ldi * cb, "identity block");
+          for (int c0 = 0; c0 < x.ni; c0 += cb) {
+            const int nc = std::min(cb, x.ni - c0);
+            launch_identity_cols<T>(I_, ldi, x.ni, c0, nc, s);
+            mf_check(hs_hss_blockop_apply(&opd, h->is_complex, (const double*)I_, ldi, (double*)(LF + (size_t)c0 * ldl), ldl, nc, 0, s));
+          }
+        } else {  // the two HSS blocks expanded in place (2 n^2 r flops each), the sparse couplings A[int1,int2], A[int2,int1] entry by entry
+          if (ch1.n1 > 0) {
+            mf_check(hs_hss_set_stream(ch1.a11, (void*)s));
+            mf_check(hs_hss_expand(ch1.a11, (double*)LF, ldl, 1));
+          }
+          if (ch2.n1 > 0) {
+            mf_check(hs_hss_set_stream(ch2.a11, (void*)s));
+            mf_check(hs_hss_expand(ch2.a11, (double*)(LF + ch1.n1 + (size_t)ch1.n1 * ldl), ldl, 1));
+          }
+          if (attempt == 0 && f12.empty() && f21.empty()) {
+            for (size_t t = 0; t < x.x12.size(); ++t) f12.push_back(HsFillEntry{x.x12.row[t], ch1.n1 + x.x12.col[t], x.x12.e[t]});
+            for (size_t t = 0; t < x.x21.size(); ++t) f21.push_back(HsFillEntry{ch1.n1 + x.x21.row[t], x.x21.col[t], x.x21.e[t]});
+          }
+          mf_fill<T>(h, f12, LF, ldl, buf, s);
+          mf_fill<T>(h, f21, LF, ldl, buf, s);
         }
         generators(LF + x.ni, ldl, UR, ldu);
         if (attempt == 0) lap("D: Aii expanded from the generators; Aib, Abi");

@@ -192,6 +192,15 @@ class HssMatrix:
     def full(self):
         return self.matmul(np.eye(self.shape[0], dtype=self.dtype))
 
+    def expand(self):
+        """``Matrix(H)`` by the expansion kernels (every basis once, then the off-diagonal products: 2 n^2 r flops), in the matrix's OWN
+        index order: ``A[perm][:, perm]`` when it was compressed with a permutation; block views carry none."""
+        n = self.shape[0]
+        out = np.zeros((n, n), dtype=self.dtype, order="F")
+        if n:
+            _lib.check(self.L.hs_hss_expand(self._h, out.ctypes.data_as(C.c_void_p), n, 0))
+        return out
+
 
 def compress(A, cl=None, *, leafsize=64, atol=1e-6, rtol=1e-6, kest=64, seed=123, pad=8, level_scale=0.5, perm=None):
     """``compress(A, cl, cl; atol, rtol)``: HSS form of the dense matrix ``A`` on the GPU (``perm``: 0-based

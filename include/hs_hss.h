@@ -90,6 +90,9 @@ int hs_hss_getindex(hs_hss* H, const int64_t* I, int64_t ni, const int64_t* J, i
  * blocks that a parent front assembles its low-rank couplings from (src/factorization.jl:129-137).  Nodes 1 and 2 are the two halves of the
  * top-level split: A12 = U_1 * B12 * U_2^T, A21 = U_2 * B21 * U_1^T with the root's B12, B21 (hs_hss_node_data). */
 int hs_hss_basis(hs_hss* H, int64_t node, double* out, int64_t ldo, int where);
+/* `Matrix(H)`: out (n x n, column-major, ldo >= n; where = 0 host / 1 device) = the matrix H represents in H's own index order
+   (a compressed matrix: A[perm, perm]; the views of hs_hss_child carry no permutation).  2 n^2 r flops. */
+int hs_hss_expand(hs_hss* H, double* out, int64_t ldo, int where);
 
 /* Y = H * X for n x nrhs blocks */
 int hs_hss_mul(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t nrhs, int where);

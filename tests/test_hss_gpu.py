@@ -134,6 +134,7 @@ def test_blocks_without_coupling(hs):
     H = hs.hss.compress(A, hs.hss.bisection_cluster((200, 400), leafsize=50), atol=1e-8, rtol=1e-8, kest=32)
     assert H._info(1)["r"] == 1 and H._info(2)["r"] == 1
     assert np.linalg.norm(H.full() - A) / np.linalg.norm(A) < 1e-6
+    assert np.linalg.norm(H.expand() - H.full()) / np.linalg.norm(A) < 1e-12  # the expansion kernels against products with the identity
     b = np.arange(400.0)
     assert np.linalg.norm(H.ldiv(b) - np.linalg.solve(A, b)) / np.linalg.norm(b) < 1e-7
     D = np.diag(np.linspace(1.0, 3.0, 300))  # every sample block is exactly zero
@@ -191,6 +192,7 @@ def test_permuted_matrix(hs):
     H0 = hs.hss.compress(K, leafsize=50, atol=1e-8, rtol=1e-8, kest=32)
     assert H.rank <= H0.rank + 6
     assert np.linalg.norm(H.full() - A) / np.linalg.norm(A) < 1e-6  # products and solves keep the caller's order
+    assert np.linalg.norm(H.expand() - K) / np.linalg.norm(K) < 1e-6  # `Matrix(H)` in the matrix's own order: A[q][:, q]
     b = np.arange(float(n))
     assert np.linalg.norm(H.ldiv(b) - np.linalg.solve(A, b)) / np.linalg.norm(b) < 1e-7
     Hbad = hs.hss.compress(A, leafsize=50, atol=1e-8, rtol=1e-8, kest=32)  # without it: ranks close to the block sizes
@@ -332,3 +334,20 @@ def test_prune_leaves_and_equilibrate_clusters(hs, complex_):
     H1 = hs.hss.compress(kernel_matrix(30, complex_), leafsize=64)
     with pytest.raises(RuntimeError, match="turned into a leaf"):
         H1.prune_leaves()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_expand_equals_products_with_the_identity(hs, dtype):
+    """`Matrix(H)` (hs_hss_expand: every basis once, then U_l*B12*U_r^T / U_r*B21*U_l^T per inner node) against H applied to the identity,
+    for the matrix and for the block views a parent front reads (hs_hss_child)."""
+    n = 700
+    K = kernel_matrix(n, complex_=(dtype == np.complex128))
+    H = hs.hss.compress(K, hs.hss.bisection_cluster((300, n), leafsize=60), atol=1e-9, rtol=1e-9, kest=32)
+    F = H.full()
+    assert np.linalg.norm(H.expand() - F) / np.linalg.norm(F) < 1e-12
+    assert np.linalg.norm(F - K) / np.linalg.norm(K) < 1e-7
+    for which, sl in ((0, slice(0, 300)), (1, slice(300, n))):
+        V = H.block(which)
+        assert np.linalg.norm(V.expand() - F[sl, sl]) / np.linalg.norm(F[sl, sl]) < 1e-12
+    Hl = hs.hss.compress(K[:40, :40], leafsize=64, atol=1e-9, rtol=1e-9, kest=16)  # a single leaf
+    assert np.allclose(Hl.expand(), K[:40, :40])
