@@ -74,7 +74,7 @@ EXPORTS = [
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned", "hs_gmres_d", "hs_gmres_z",
     "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
-    "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
+    "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_compress_lru_multi_d", "hs_hss_compress_lru_multi_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_expand", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free", "hs_node_schur_hss",
     "hs_hss_offdiag", "hs_hss_bytes", "hs_hss_prune_leaves", "hs_hss_compatible", "hs_hss_depth", "hs_hss_compress_blockop_d", "hs_hss_compress_blockop_z", "hs_hss_blockop_apply",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_mfma_f64_peak_random", "hsk_bisect_perm",
@@ -209,6 +209,10 @@ def lib():
         f.restype = C.c_int
     for f in (L.hs_hss_compress_lru_d, L.hs_hss_compress_lru_z):
         f.argtypes = [i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, C.c_int, p_i64, C.POINTER(hs_hss_options), vp, C.POINTER(vp)]
+        f.restype = C.c_int
+    for f in (L.hs_hss_compress_lru_multi_d, L.hs_hss_compress_lru_multi_z):
+        f.argtypes = [i64, p_i64, C.POINTER(vp), p_i64, C.POINTER(vp), p_i64, C.POINTER(vp), p_i64, C.POINTER(vp), p_i64, p_i64, p_i64, C.POINTER(p_i64),
+                      C.POINTER(C.POINTER(hs_hss_options)), vp, C.POINTER(vp)]
         f.restype = C.c_int
     for f in (L.hs_hss_rank, L.hs_hss_size, L.hs_hss_samples, L.hs_hss_num_nodes, L.hs_hss_bytes):
         f.argtypes = [vp]

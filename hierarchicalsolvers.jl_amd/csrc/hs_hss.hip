@@ -96,6 +96,7 @@ struct SubJob {
   int ldo, trans;  // trans: the result is written transposed (out is cols x rows)
   const int* hri = nullptr;  // HOST copies of ri / ci (+ r0 / c0 already added: absolute indices), for operators that route the
   const int* hci = nullptr;  // request on the host (BlockOp::gather); null: the range r0 + i
+  int blk = 0;               // batched compression: which of the matrices A belongs to (its low-rank update corrects the block)
 };
 template <class T>
 __global__ __launch_bounds__(64) void sub_gather_kernel(const SubJob<T>* __restrict__ jobs) {
@@ -374,6 +375,7 @@ struct HssT {
   NodeDesc<T> rootfd;  // LU of the last block
   int root_m = 0;
   double t_compress = 0.0, t_factor = 0.0;
+  std::shared_ptr<void> hold;  // a matrix of a batched compression: the forest that owns its generators lives as long as any of them
   ~HssT() {
     if (s && own_stream) (void)hipStreamDestroy(s);
   }
@@ -935,9 +937,27 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
 
 template <class T>
 struct BlockOp;  // hs_hss_op.h: [H1 A12; A21 H2] of two HSS blocks and sparse couplings, never formed
+// One matrix of a BATCHED compression: the fronts of a tree level hand over Schur complements of the same kind, and compressed one by one
+// each is a chain of ~10,000 small dependent launches (110 ms for n = 12,097 whatever the chip could do besides).  compress_fixed
+// therefore works on a FOREST: the cluster trees of all the matrices side by side in one node array (roots at level 0, the index space
+// concatenated), every stage of a tree level one group of launches for all of them.  One matrix = a forest of one tree.
 template <class T>
-bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = Lru<T>(), BlockOp<T>* bop = nullptr) {
+struct CBlock {
+  const T* A = nullptr;  // the matrix (device), or null with an operator
+  int lda = 0, n = 0, off = 0;        // its rows are [off, off + n) of the concatenated index space
+  const int* perm = nullptr;          // device: H ~= A[perm, perm] (values local to the block), or null
+  const int* hperm = nullptr;         // the same on the host
+  Lru<T> lru;
+  int leafsize = 64, first_split = 0;
+  uint64_t seed = 0;
+  int root = 0;                       // node of its root (set by compress_fixed)
+  T* MT = nullptr;                    // M^T of its update (work)
+  double gscale = 0.0, gscale_q = 0.0;  // largest sample pivot / row norm seen so far: the scale of ITS off-diagonal part
+};
+template <class T>
+bool compress_fixed(HssT<T>& H, std::vector<CBlock<T>>& cb, int k, BlockOp<T>* bop = nullptr) {
   const int n = H.n;
+  const int F = (int)cb.size();
   hipStream_t s = H.s;
   Pool tmp(global_cache());  // samples and everything else that dies with this attempt
   static const bool vtime = getenv("HS_HSS_VERBOSE") != nullptr;  // diagnostics: wall time of every phase (adds synchronisations)
@@ -950,18 +970,53 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     vt0 = now;
   };
   H.keep.clear();
-  build_tree(H, n, (int)H.opt.leafsize, (int)H.opt.first_split);
+  std::vector<int> nblk;  // node -> matrix
+  if (F == 1) {
+    build_tree(H, n, cb[0].leafsize, cb[0].first_split);
+    cb[0].root = 0;
+    cb[0].off = 0;
+    nblk.assign(H.nd.size(), 0);
+  } else {  // the trees side by side: node ids and index ranges shifted, every root at level 0
+    H.nd.clear();
+    int off = 0;
+    for (int b = 0; b < F; ++b) {
+      HssT<T> one;
+      build_tree(one, cb[b].n, cb[b].leafsize, cb[b].first_split);
+      const int base = (int)H.nd.size();
+      cb[b].root = base;
+      cb[b].off = off;
+      for (HNode<T> y : one.nd) {
+        y.lo += off;
+        y.hi += off;
+        if (y.parent >= 0) y.parent += base;
+        if (y.left >= 0) {
+          y.left += base;
+          y.right += base;
+        }
+        H.nd.push_back(y);
+        nblk.push_back(b);
+      }
+      off += cb[b].n;
+    }
+    H.nlev = 0;
+    for (auto& x : H.nd) H.nlev = std::max(H.nlev, x.level + 1);
+    H.lev.assign(H.nlev, {});
+    for (int i = 0; i < (int)H.nd.size(); ++i) H.lev[H.nd[i].level].push_back(i);
+  }
   H.k = k;
   const int k2 = 2 * k, ldn = ev(n), ldk = ev(k);
   auto& nd = H.nd;
   std::vector<SubJob<T>> subs;
   std::vector<RowJob<T>> rows;
   std::vector<GemmProb<T>> gemms;
-  T* MT = nullptr;  // M^T for the transposed gathers
-  if (lru.on() && lru.M) {
-    MT = tmp.get<T>((size_t)ev(lru.r2) * lru.r1);
-    std::vector<SubJob<T>> one{SubJob<T>{lru.M, lru.ldm, nullptr, nullptr, 0, 0, lru.r1, lru.r2, MT, ev(lru.r2), 1}};
-    run_subs(tmp, one, s);
+  {  // M^T for the transposed gathers
+    std::vector<SubJob<T>> tr;
+    for (auto& B : cb)
+      if (B.lru.on() && B.lru.M) {
+        B.MT = tmp.get<T>((size_t)ev(B.lru.r2) * B.lru.r1);
+        tr.push_back(SubJob<T>{B.lru.M, B.lru.ldm, nullptr, nullptr, 0, 0, B.lru.r1, B.lru.r2, B.MT, ev(B.lru.r2), 1});
+      }
+    run_subs(tmp, tr, s);
   }
   // blocks of A by index lists (the jobs in `subs` all read A): B's entries, minus the low-rank update's
   auto gather_A = [&]() {
@@ -972,10 +1027,12 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     } else {
       run_subs(tmp, subs, s);
     }
-    if (!lru.on()) return;
     std::vector<SubJob<T>> pieces;
     std::vector<GemmProb<T>> g1, g2;
     for (const SubJob<T>& j : jobs) {
+      const Lru<T>& lru = cb[j.blk].lru;
+      T* MT = cb[j.blk].MT;
+      if (!lru.on()) continue;
       if (j.rows <= 0 || j.cols <= 0) continue;
       const int r1 = lru.r1, r2 = lru.r2;
       if (!j.trans) {
@@ -1000,12 +1057,18 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     run_gemms(tmp, g1, 0, s);
     run_gemms(tmp, g2, 1, s);
   };
-  if (nd[0].left < 0) {  // a single leaf: H = D
+  if (F > 1) {
+    for (auto& B : cb)
+      if (nd[B.root].left < 0 || bop) {
+        hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: a batched compression needs matrices (no operators) of at least two leaves each");
+        throw (int)HS_ERR_ARGUMENT;
+      }
+  } else if (nd[0].left < 0) {  // a single leaf: H = D
     HNode<T>& x = nd[0];
     x.m = n;
     x.ldd = ev(n);
     x.D = H.keep.template get<T>((size_t)x.ldd * n);
-    subs.push_back(SubJob<T>{A, lda, H.perm, H.perm, 0, 0, n, n, x.D, x.ldd, 0, H.hperm.empty() ? nullptr : H.hperm.data(), H.hperm.empty() ? nullptr : H.hperm.data()});
+    subs.push_back(SubJob<T>{cb[0].A, cb[0].lda, cb[0].perm, cb[0].perm, 0, 0, n, n, x.D, x.ldd, 0, cb[0].hperm, cb[0].hperm});
     gather_A();
     HSS_HIP(hipStreamSynchronize(s));
     return true;
@@ -1016,12 +1079,14 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
   T* Y = tmp.get<T>((size_t)ldn * k2);
   T* PsT = tmp.get<T>((size_t)ldk * n);
   T* W = tmp.get<T>((size_t)ldk * n);
-  fill_randn<T>(OP, n, ldn, k2, (uint64_t)H.opt.seed * 0x9E3779B97F4A7C15ull + 17 * (uint64_t)k, s);
+  fill_randn<T>(OP, n, ldn, k2, (uint64_t)cb[0].seed * 0x9E3779B97F4A7C15ull + 17 * (uint64_t)k, s);
   T *OPs = OP, *Ys = Y;
-  if (H.perm) {
+  bool any_perm = false;
+  for (auto& B : cb) any_perm = any_perm || B.perm != nullptr;
+  if (any_perm) {
     OPs = tmp.get<T>((size_t)ldn * k2);
     Ys = tmp.get<T>((size_t)ldn * k2);
-    rows.push_back(RowJob<T>{OP, ldn, OPs, ldn, H.perm, n, k2, ROW_SCATTER});
+    for (auto& B : cb) rows.push_back(RowJob<T>{OP + B.off, ldn, OPs + B.off, ldn, B.perm, B.n, k2, B.perm ? ROW_SCATTER : ROW_GATHER});
     run_rows(tmp, rows, s);
   }
   subs.push_back(SubJob<T>{OPs + (size_t)ldn * k, ldn, nullptr, nullptr, 0, 0, n, k, PsT, ldk, 1});
@@ -1033,32 +1098,39 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     subs.push_back(SubJob<T>{Y2, ldn, nullptr, nullptr, 0, 0, n, k, W, ldk, 1});
     run_subs(tmp, subs, s);
   } else {
-    gemms.push_back(GemmProb<T>{A, OPs, Ys, n, k, n, lda, ldn, ldn});
-    gemms.push_back(GemmProb<T>{PsT, A, W, k, n, n, ldk, lda, ldk});
+    for (auto& B : cb) {
+      gemms.push_back(GemmProb<T>{B.A, OPs + B.off, Ys + B.off, B.n, k, B.n, B.lda, ldn, ldn});
+      gemms.push_back(GemmProb<T>{PsT + (size_t)B.off * ldk, B.A, W + (size_t)B.off * ldk, k, B.n, B.n, ldk, B.lda, ldk});
+    }
     run_gemms(tmp, gemms, 0, s);
   }
-  if (lru.on()) {  // Ys -= C*(M*(Z*OPs)),  W -= ((PsT*C)*M)*Z
-    const int r1 = lru.r1, r2 = lru.r2;
-    T* t1 = tmp.getz<T>((size_t)ev(r2) * k, s);
-    T* u1 = tmp.getz<T>((size_t)ldk * r1, s);
-    T* t2 = lru.M ? tmp.getz<T>((size_t)ev(r1) * k, s) : t1;  // M == nullptr: the identity (r1 == r2)
-    T* u2 = lru.M ? tmp.getz<T>((size_t)ldk * r2, s) : u1;
-    gemms.push_back(GemmProb<T>{lru.Z, OPs, t1, r2, k, n, lru.ldz, ldn, ev(r2)});
-    gemms.push_back(GemmProb<T>{PsT, lru.C, u1, k, r1, n, ldk, lru.ldc, ldk});
-    run_gemms(tmp, gemms, 0, s);
-    if (lru.M) {
-      gemms.push_back(GemmProb<T>{lru.M, t1, t2, r1, k, r2, lru.ldm, ev(r2), ev(r1)});
-      gemms.push_back(GemmProb<T>{u1, lru.M, u2, k, r2, r1, ldk, lru.ldm, ldk});
-      run_gemms(tmp, gemms, 0, s);
+  {  // Ys -= C*(M*(Z*OPs)),  W -= ((PsT*C)*M)*Z for the matrices that carry a low-rank update
+    std::vector<GemmProb<T>> ga, gb, gc;
+    for (auto& B : cb) {
+      const Lru<T>& lru = B.lru;
+      if (!lru.on()) continue;
+      const int r1 = lru.r1, r2 = lru.r2;
+      T* t1 = tmp.getz<T>((size_t)ev(r2) * k, s);
+      T* u1 = tmp.getz<T>((size_t)ldk * r1, s);
+      T* t2 = lru.M ? tmp.getz<T>((size_t)ev(r1) * k, s) : t1;  // M == nullptr: the identity (r1 == r2)
+      T* u2 = lru.M ? tmp.getz<T>((size_t)ldk * r2, s) : u1;
+      ga.push_back(GemmProb<T>{lru.Z, OPs + B.off, t1, r2, k, B.n, lru.ldz, ldn, ev(r2)});
+      ga.push_back(GemmProb<T>{PsT + (size_t)B.off * ldk, lru.C, u1, k, r1, B.n, ldk, lru.ldc, ldk});
+      if (lru.M) {
+        gb.push_back(GemmProb<T>{lru.M, t1, t2, r1, k, r2, lru.ldm, ev(r2), ev(r1)});
+        gb.push_back(GemmProb<T>{u1, lru.M, u2, k, r2, r1, ldk, lru.ldm, ldk});
+      }
+      gc.push_back(GemmProb<T>{lru.C, t2, Ys + B.off, B.n, k, r1, lru.ldc, ev(r1), ldn});
+      gc.push_back(GemmProb<T>{u2, lru.Z, W + (size_t)B.off * ldk, k, B.n, r2, ldk, lru.ldz, ldk});
     }
-    gemms.push_back(GemmProb<T>{lru.C, t2, Ys, n, k, r1, lru.ldc, ev(r1), ldn});
-    gemms.push_back(GemmProb<T>{u2, lru.Z, W, k, n, r2, ldk, lru.ldz, ldk});
-    run_gemms(tmp, gemms, 1, s);
+    run_gemms(tmp, ga, 0, s);
+    run_gemms(tmp, gb, 0, s);
+    run_gemms(tmp, gc, 1, s);
   }
   subs.push_back(SubJob<T>{W, ldk, nullptr, nullptr, 0, 0, k, n, Ys + (size_t)ldn * k, ldn, 1});
   run_subs(tmp, subs, s);
-  if (H.perm) {
-    rows.push_back(RowJob<T>{Ys, ldn, Y, ldn, H.perm, n, k2, ROW_GATHER});
+  if (any_perm) {
+    for (auto& B : cb) rows.push_back(RowJob<T>{Ys + B.off, ldn, Y + B.off, ldn, B.perm, B.n, k2, ROW_GATHER});
     run_rows(tmp, rows, s);
   }
 
@@ -1075,8 +1147,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       Ol[i] = OP + nd[i].lo;
       ldl[i] = ldn;
     }
-  double gscale = 0.0;  // largest sample pivot seen so far (deeper levels): the scale of the matrix's off-diagonal part
-  double gscale_q = 0.0;  // the same in terms of the row norms of the orthogonalisation (qr_refine)
+  for (auto& B : cb) B.gscale = B.gscale_q = 0.0;  // largest sample pivot / row norm seen so far (deeper levels), per matrix
   for (int lv = H.nlev - 1; lv >= 1; --lv) {
     const std::vector<int>& L = H.lev[lv];
     const int nj = (int)L.size();
@@ -1085,15 +1156,20 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     for (int i : L) {
       HNode<T>& x = nd[i];
       const int m = x.m;
+      const int bi = nblk[i];
+      const CBlock<T>& B = cb[bi];
+      const T* A = B.A;
+      const int lda = B.lda;
       if (x.left < 0) {
         x.ldd = ev(m);
         x.D = H.keep.template get<T>((size_t)x.ldd * m);
         DT[i] = tmp.get<T>((size_t)x.ldd * m);
-        const int* pl = H.perm ? H.perm + x.lo : nullptr;  // rows / columns of A behind the leaf's positions
-        const int o0 = H.perm ? 0 : x.lo;
-        const int* hpl = H.hperm.empty() ? nullptr : H.hperm.data() + x.lo;
-        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, x.D, x.ldd, 0, hpl, hpl});
-        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, DT[i], x.ldd, 1, hpl, hpl});
+        const int lo_loc = x.lo - B.off;
+        const int* pl = B.perm ? B.perm + lo_loc : nullptr;  // rows / columns of A behind the leaf's positions
+        const int o0 = B.perm ? 0 : lo_loc;
+        const int* hpl = B.hperm ? B.hperm + lo_loc : nullptr;
+        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, x.D, x.ldd, 0, hpl, hpl, bi});
+        subs.push_back(SubJob<T>{A, lda, pl, pl, o0, o0, m, m, DT[i], x.ldd, 1, hpl, hpl, bi});
         gemms.push_back(GemmProb<T>{x.D, Ol[i], Yl[i], m, k, m, x.ldd, ldl[i], ldl[i]});
         gemms.push_back(GemmProb<T>{DT[i], Ol[i] + (size_t)ldl[i] * k, Yl[i] + (size_t)ldl[i] * k, m, k, m, x.ldd, ldl[i], ldl[i]});
       } else {
@@ -1105,10 +1181,10 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
         x.B21 = H.keep.template get<T>((size_t)x.ld21 * rl);
         B12T[i] = tmp.get<T>((size_t)x.ld21 * rl);  // rr x rl
         B21T[i] = tmp.get<T>((size_t)x.ld12 * rr);  // rl x rr
-        subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, rl, rr, x.B12, x.ld12, 0, l.hsk.data(), r.hsk.data()});
-        subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, rr, rl, x.B21, x.ld21, 0, r.hsk.data(), l.hsk.data()});
-        subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, rl, rr, B12T[i], x.ld21, 1, l.hsk.data(), r.hsk.data()});
-        subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, rr, rl, B21T[i], x.ld12, 1, r.hsk.data(), l.hsk.data()});
+        subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, rl, rr, x.B12, x.ld12, 0, l.hsk.data(), r.hsk.data(), bi});
+        subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, rr, rl, x.B21, x.ld21, 0, r.hsk.data(), l.hsk.data(), bi});
+        subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, rl, rr, B12T[i], x.ld21, 1, l.hsk.data(), r.hsk.data(), bi});
+        subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, rr, rl, B21T[i], x.ld12, 1, r.hsk.data(), l.hsk.data(), bi});
         T *Yi = Yl[i], *Oi = Ol[i];
         const size_t ck = (size_t)ld * k;
         gemms.push_back(GemmProb<T>{x.B12, Oi + rl, Yi, rl, k, rr, x.ld12, ld, ld});              // Sr_l -= B12 * Om~_r
@@ -1126,7 +1202,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     for (int a = 0; a < nj; ++a) {
       const int i = L[a];
       // sketch width k: the adaptive rule below keeps every rank under k - pad (a block that gets closer is redone at 2k by the ID itself)
-      jobs[a] = LowRankJob<T>{Yl[i], ldl[i], nd[i].m, k2, k, (uint64_t)H.opt.seed + 7919ull * (uint64_t)i, &lr[a], 0};
+      jobs[a] = LowRankJob<T>{Yl[i], ldl[i], nd[i].m, k2, k, cb[nblk[i]].seed + 7919ull * (uint64_t)(i - cb[nblk[i]].root), &lr[a], 0};
     }
     run_rows(tmp, rows, s);
     // deeper levels are truncated more tightly: the error they hand up must stay below the threshold of the levels above
@@ -1135,8 +1211,10 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     const double lsc = std::pow(H.opt.level_scale, lv - 1);
     // the relative tolerance refers to the block's own largest pivot, but never to less than the largest one met below: a block
     // that couples weakly (or not at all) is noise of the children's truncation, and relative to ITSELF noise has full rank
+    double gscale = 0.0;  // (the tolerance only matters to the LU-based rank rule, HS_HSS_QR=0: the largest scale of the batch)
+    for (auto& B : cb) gscale = std::max(gscale, B.gscale);
     const int st = lowrank_compress_batch<T>(jobs.data(), nj, std::max(H.opt.atol, H.opt.rtol * gscale) * lsc, H.opt.rtol * lsc, s, false);
-    for (int a = 0; a < nj; ++a) gscale = std::max(gscale, lr[a].top);
+    for (int a = 0; a < nj; ++a) cb[nblk[L[a]]].gscale = std::max(cb[nblk[L[a]]].gscale, lr[a].top);
     vlap("pivot order (tournament LU of sketches)", lv);
     auto free_lr = [&]() {
       for (auto& q : lr) lowrank_free(q);
@@ -1158,14 +1236,15 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
         qj[a].q = k2;
         qj[a].p = lr[a].rperm;
         qj[a].rmax = lr[a].k;  // the pivoted LU ordered the first k (sketch width) rows; the orthogonalisation stops by itself once a block of 32 rows is below the threshold
+        qj[a].atol_scale = std::max(H.opt.atol, H.opt.rtol * cb[nblk[i]].gscale_q);  // absolute threshold of ITS matrix (times lsc below)
       }
       try {
-        qr_refine<T>(tmp, H.keep, qj, std::max(H.opt.atol, H.opt.rtol * gscale_q) * lsc, H.opt.rtol * lsc, 0.0, s);
+        qr_refine<T>(tmp, H.keep, qj, lsc, H.opt.rtol * lsc, 0.0, s);
       } catch (...) {
         free_lr();
         throw;
       }
-      for (int a = 0; a < nj; ++a) gscale_q = std::max(gscale_q, qj[a].top);
+      for (int a = 0; a < nj; ++a) cb[nblk[L[a]]].gscale_q = std::max(cb[nblk[L[a]]].gscale_q, qj[a].top);
       vlap("rank + interpolation (qr_refine)", lv);
     }
     bool enough = true;
@@ -1176,7 +1255,7 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
       // a sketch of k samples is trusted up to rank 0.8*k - pad: the spectra of separator blocks decay slowly, and a rank within a few
       // per cent of k means the tail beyond the sketch was never seen (measured on the 32,768 root of Poisson 128^3: rank 2,016 of 2,048
       // samples left a residual of 0.5 where 4,096 samples give 2e-3)
-      if (r > (int)(0.8 * k) - (int)H.opt.pad && r < m && k < n) enough = false;
+      if (r > (int)(0.8 * k) - (int)H.opt.pad && r < m && k < cb[nblk[L[a]]].n) enough = false;
       nd[L[a]].r = r;
     }
     static const bool verbose = getenv("HS_HSS_VERBOSE") != nullptr;
@@ -1221,7 +1300,11 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
           else  // the sample block is zero (the node does not couple to the rest at all): one nominal skeleton position, T = 0 --
             HSS_HIP(hipMemsetAsync(x.Tm, 0, sizeof(T) * (size_t)x.ldt * r, s));  // the L\U of a zero sketch holds nothing usable
         }
-        ij.push_back(IdxJob{x.p, (x.left < 0 && H.perm) ? H.perm + x.lo : Jidx[i], x.lo, r, x.sk});
+        {
+          const CBlock<T>& B = cb[nblk[i]];
+          const int lo_loc = x.lo - B.off;  // skeleton indices are local to the node's matrix
+          ij.push_back(IdxJob{x.p, (x.left < 0 && B.perm) ? B.perm + lo_loc : Jidx[i], lo_loc, r, x.sk});
+        }
         maxR = std::max(maxR, nR);
         maxr = std::max(maxr, r);
       }
@@ -1333,19 +1416,19 @@ bool compress_fixed(HssT<T>& H, const T* A, int lda, int k, const Lru<T>& lru = 
     free_lr();
     vlap("skeletons handed to the parents", lv);
   }
-  // root: couplings of its two children
-  {
-    HNode<T>& x = nd[0];
+  // roots: couplings of their two children
+  for (int b = 0; b < F; ++b) {
+    HNode<T>& x = nd[cb[b].root];
     const HNode<T>&l = nd[x.left], &r = nd[x.right];
     x.m = l.r + r.r;
     x.ld12 = ev(l.r);
     x.ld21 = ev(r.r);
     x.B12 = H.keep.template get<T>((size_t)x.ld12 * r.r);
     x.B21 = H.keep.template get<T>((size_t)x.ld21 * l.r);
-    subs.push_back(SubJob<T>{A, lda, l.sk, r.sk, 0, 0, l.r, r.r, x.B12, x.ld12, 0, l.hsk.data(), r.hsk.data()});
-    subs.push_back(SubJob<T>{A, lda, r.sk, l.sk, 0, 0, r.r, l.r, x.B21, x.ld21, 0, r.hsk.data(), l.hsk.data()});
-    gather_A();
+    subs.push_back(SubJob<T>{cb[b].A, cb[b].lda, l.sk, r.sk, 0, 0, l.r, r.r, x.B12, x.ld12, 0, l.hsk.data(), r.hsk.data(), b});
+    subs.push_back(SubJob<T>{cb[b].A, cb[b].lda, r.sk, l.sk, 0, 0, r.r, l.r, x.B21, x.ld21, 0, r.hsk.data(), l.hsk.data(), b});
   }
+  gather_A();
   HSS_HIP(hipStreamSynchronize(s));
   return true;
 }
@@ -2023,7 +2106,13 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
   if (bop) bop->begin(H->s);
   try {
     for (;;) {
-      if (compress_fixed<T>(*H, dA, ld, k, lru, bop)) break;
+      std::vector<CBlock<T>> cb(1);
+      cb[0].A = dA; cb[0].lda = ld; cb[0].n = (int)n; cb[0].off = 0;
+      cb[0].perm = H->perm; cb[0].hperm = H->hperm.empty() ? nullptr : H->hperm.data();
+      cb[0].lru = lru;
+      cb[0].leafsize = (int)H->opt.leafsize; cb[0].first_split = (int)H->opt.first_split;
+      cb[0].seed = (uint64_t)H->opt.seed;
+      if (compress_fixed<T>(*H, cb, k, bop)) break;
       if (k >= n) break;
       k = (int)std::min<int64_t>(2 * (int64_t)k, n);
     }
@@ -2315,12 +2404,12 @@ extern "C" int hs_hss_mul_t(hs_hss* H, const double* X, int64_t ldx, double* Y, 
 // `H.A11` (which = 0) / `H.A22` (which = 1): the diagonal block of the top-level split as an HSS matrix of its own that SHARES the
 // generators of H (H must outlive it).  Its index space is the block's own: 0 .. size-1 in the order of the cluster tree.
 template <class T>
-static HssT<T>* child_impl(HssT<T>* P, int which) {
+static HssT<T>* child_impl(HssT<T>* P, int which, int top_node = -1) {
   if (P->nd[0].left < 0 && which != 2) {
     hs_set_error(HS_ERR_HSS_LEAF, 0, "One of the Schur complements turned into a leaf. Aborting.");  // factorization.jl:164
     throw (int)HS_ERR_HSS_LEAF;
   }
-  const int top = which == 2 ? 0 : (which == 0 ? P->nd[0].left : P->nd[0].right);
+  const int top = top_node >= 0 ? top_node : (which == 2 ? 0 : (which == 0 ? P->nd[0].left : P->nd[0].right));  // top_node: a root of a forest
   const int off = P->nd[top].lo;
   std::vector<int> ids, cur{top};
   while (!cur.empty()) {  // breadth-first renumbering of the subtree
@@ -2607,6 +2696,144 @@ static void offdiag_impl(HssT<T>& H, int which, T* C_, int ldc, T* Z, int ldz) {
   run_subs(tmp, t, s);
   HSS_HIP(hipStreamSynchronize(s));
 }
+// Batched compression of `count` matrices B_b - C_b*M_b*Z_b (device operands), each with its own permutation, first split and leaf size:
+// ONE forest compressed level by level (compress_fixed), then one view per matrix that shares the forest's generators and keeps it alive.
+// atol, rtol, pad, level_scale are those of the first options block; the number of samples is common (the largest kest, doubled until
+// every matrix passes the rank rule).
+template <class T>
+static void compress_multi_impl(int64_t count, const int64_t* n, const T* const* A, const int64_t* lda, const LruArgs* la, const int64_t* const* perm,
+                                const hs_hss_options* const* opts, void* stream, hs_hss** out) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+    hs_set_error(HS_ERR_DEVICE, 0, "no HIP device available (the HSS module has no CPU fallback)");
+    throw (int)HS_ERR_DEVICE;
+  }
+  if (count <= 0 || !n || !A || !lda || !opts || !out) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: incomplete batched compression");
+    throw (int)HS_ERR_ARGUMENT;
+  }
+  int64_t ntot = 0;
+  for (int64_t b = 0; b < count; ++b) {
+    if (n[b] <= 0 || !A[b] || lda[b] < n[b] || !opts[b] || opts[b]->leafsize < 1 || opts[b]->first_split < 0 || opts[b]->first_split > n[b]) {
+      hs_set_error(HS_ERR_ARGUMENT, b, "ArgumentError: matrix %lld of a batched compression needs n > 0, lda >= n, options", (long long)b);
+      throw (int)HS_ERR_ARGUMENT;
+    }
+    ntot += n[b];
+  }
+  if (ntot > (1 << 30)) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: batched compression too large");
+    throw (int)HS_ERR_ARGUMENT;
+  }
+  hs_hss_options opt = *opts[0];
+  if (opt.pad <= 0) opt.pad = 8;
+  if (!(opt.level_scale > 0.0) || opt.level_scale > 1.0) opt.level_scale = 0.5;
+  std::shared_ptr<HssT<T>> H(new HssT<T>());
+  H->n = (int)ntot;
+  H->opt = opt;
+  if (stream) {
+    H->s = (hipStream_t)stream;
+  } else {
+    HSS_HIP(hipStreamCreate(&H->s));
+    H->own_stream = true;
+  }
+  std::vector<CBlock<T>> cb((size_t)count);
+  std::vector<std::vector<int>> hps((size_t)count);
+  int* dperm = H->permpool.template get<int>((size_t)ntot);
+  int64_t off = 0, kest = 8, nmax = 0;
+  for (int64_t b = 0; b < count; ++b) {
+    CBlock<T>& B = cb[(size_t)b];
+    B.A = A[b]; B.lda = (int)lda[b]; B.n = (int)n[b];
+    B.leafsize = (int)opts[b]->leafsize; B.first_split = (int)opts[b]->first_split;
+    B.seed = (uint64_t)opts[b]->seed;
+    kest = std::max<int64_t>(kest, opts[b]->kest > 0 ? opts[b]->kest : 64);
+    nmax = std::max(nmax, n[b]);
+    if (perm && perm[b]) {
+      std::vector<int>& hp = hps[(size_t)b];
+      hp.resize((size_t)n[b]);
+      std::vector<char> seen((size_t)n[b], 0);
+      for (int64_t i = 0; i < n[b]; ++i) {
+        if (perm[b][i] < 0 || perm[b][i] >= n[b] || seen[(size_t)perm[b][i]]) {
+          hs_set_error(HS_ERR_ARGUMENT, i, "ArgumentError: perm is not a permutation of 0..n-1 (entry %lld)", (long long)i);
+          throw (int)HS_ERR_ARGUMENT;
+        }
+        seen[(size_t)perm[b][i]] = 1;
+        hp[(size_t)i] = (int)perm[b][i];
+      }
+      HSS_HIP(hipMemcpy(dperm + off, hp.data(), sizeof(int) * (size_t)n[b], hipMemcpyHostToDevice));
+      B.perm = dperm + off;
+      B.hperm = hp.data();
+    }
+    if (la && la[b].r1 > 0 && la[b].r2 > 0) {
+      const LruArgs& a = la[b];
+      const bool m_id = !a.M && a.r1 == a.r2;
+      if (!a.C || (!a.M && !m_id) || !a.Z || a.ldc < n[b] || (a.M && a.ldm < a.r1) || a.ldz < a.r2 || a.r1 > n[b] || a.r2 > n[b]) {
+        hs_set_error(HS_ERR_DIMENSION, b, "DimensionMismatch: the low-rank update needs C (n x r1), M (r1 x r2), Z (r2 x n)");
+        throw (int)HS_ERR_DIMENSION;
+      }
+      B.lru.C = (const T*)a.C; B.lru.ldc = (int)a.ldc;
+      B.lru.M = (const T*)a.M; B.lru.ldm = (int)a.ldm;
+      B.lru.Z = (const T*)a.Z; B.lru.ldz = (int)a.ldz;
+      B.lru.r1 = (int)a.r1; B.lru.r2 = (int)a.r2;
+    }
+    off += n[b];
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  int k = (int)std::min<int64_t>(kest, nmax);
+  for (;;) {
+    if (compress_fixed<T>(*H, cb, k, nullptr)) break;
+    if (k >= nmax) break;
+    k = (int)std::min<int64_t>(2 * (int64_t)k, nmax);
+  }
+  const double tc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int64_t b = 0; b < count; ++b) out[b] = nullptr;
+  try {
+    for (int64_t b = 0; b < count; ++b) {
+      HssT<T>* V = child_impl<T>(H.get(), 2, cb[(size_t)b].root);
+      V->hold = H;
+      V->opt = *opts[b];
+      V->opt.pad = opt.pad;
+      V->opt.level_scale = opt.level_scale;
+      V->k = H->k;
+      V->t_compress = tc / (double)count;
+      if (cb[(size_t)b].perm) {
+        V->perm = const_cast<int*>(cb[(size_t)b].perm);  // lives in the forest's pool
+        V->hperm = hps[(size_t)b];
+        V->hinvperm.assign((size_t)n[b], 0);
+        for (int64_t i = 0; i < n[b]; ++i) V->hinvperm[(size_t)V->hperm[(size_t)i]] = (int)i;
+      }
+      out[b] = new hs_hss{sizeof(T) == 16, V};
+    }
+  } catch (...) {
+    for (int64_t b = 0; b < count; ++b)
+      if (out[b]) {
+        hs_hss_free(out[b]);
+        out[b] = nullptr;
+      }
+    throw;
+  }
+}
+
+extern "C" int hs_hss_compress_lru_multi_d(int64_t count, const int64_t* n, const double* const* B, const int64_t* ldb, const double* const* C_, const int64_t* ldc,
+                                           const double* const* M, const int64_t* ldm, const double* const* Z, const int64_t* ldz, const int64_t* r1, const int64_t* r2,
+                                           const int64_t* const* perm, const hs_hss_options* const* opts, void* stream, hs_hss** out) {
+  if (!out || count <= 0) return HS_ERR_ARGUMENT;
+  HSS_GUARD(
+      std::vector<LruArgs> la((size_t)count);
+      for (int64_t b = 0; b < count; ++b)
+        if (r1 && r2 && r1[b] > 0 && r2[b] > 0) la[(size_t)b] = LruArgs{C_[b], M ? M[b] : nullptr, Z[b], ldc[b], ldm ? ldm[b] : 0, ldz[b], r1[b], r2[b]};
+      compress_multi_impl<double>(count, n, B, ldb, la.data(), perm, opts, stream, out));
+}
+extern "C" int hs_hss_compress_lru_multi_z(int64_t count, const int64_t* n, const double* const* B, const int64_t* ldb, const double* const* C_, const int64_t* ldc,
+                                           const double* const* M, const int64_t* ldm, const double* const* Z, const int64_t* ldz, const int64_t* r1, const int64_t* r2,
+                                           const int64_t* const* perm, const hs_hss_options* const* opts, void* stream, hs_hss** out) {
+  if (!out || count <= 0) return HS_ERR_ARGUMENT;
+  HSS_GUARD(
+      std::vector<LruArgs> la((size_t)count);
+      for (int64_t b = 0; b < count; ++b)
+        if (r1 && r2 && r1[b] > 0 && r2[b] > 0) la[(size_t)b] = LruArgs{C_[b], M ? M[b] : nullptr, Z[b], ldc[b], ldm ? ldm[b] : 0, ldz[b], r1[b], r2[b]};
+      compress_multi_impl<cplx>(count, n, (const cplx* const*)B, ldb, la.data(), perm, opts, stream, out));
+}
+
 extern "C" int hs_hss_expand(hs_hss* H, double* out, int64_t ldo, int where) {
   if (!H || !out || ldo < hs_hss_size(H)) {
     hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_expand needs an n x n result (ldo >= n)");

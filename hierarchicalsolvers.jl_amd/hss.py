@@ -254,6 +254,52 @@ def compress_lowrank_update(B, Cm, M, Z, cl=None, *, leafsize=64, atol=1e-6, rto
     return HssMatrix(h, is_c)
 
 
+def compress_lowrank_update_batch(items, *, leafsize=64, atol=1e-6, rtol=1e-6, kest=64, seed=123, pad=8, level_scale=0.5, device="cuda:0"):
+    """``compress_lowrank_update`` for several operators at once (``hs_hss_compress_lru_multi``): the Schur complements of the fronts of one
+    tree level, compressed as ONE forest so that a stage of a cluster-tree level is one group of launches for all of them.
+    ``items``: dicts with ``B`` and optionally ``C, M, Z`` (the update), ``perm``, ``cl = (first_split, n, leafsize)``."""
+    import torch
+
+    cnt = len(items)
+    is_c = any(np.iscomplexobj(it[k]) for it in items for k in ("B", "C", "M", "Z") if it.get(k) is not None)
+    dt = np.complex128 if is_c else np.float64
+    keep, perms, opts = [], [], []
+
+    def dev(a):  # column-major on the device
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a).astype(dt).T)).to(device)
+        keep.append(t)
+        return t.data_ptr()
+
+    n = (C.c_int64 * cnt)()
+    ldb, ldc, ldm, ldz, r1, r2 = ((C.c_int64 * cnt)() for _ in range(6))
+    Bp, Cp, Mp, Zp = ((C.c_void_p * cnt)() for _ in range(4))
+    pp = (_lib.p_i64 * cnt)()
+    op = (C.POINTER(_lib.hs_hss_options) * cnt)()
+    for b, it in enumerate(items):
+        Bm = np.asarray(it["B"])
+        nb = Bm.shape[0]
+        n[b], ldb[b], Bp[b] = nb, nb, dev(Bm)
+        if it.get("C") is not None:
+            Cm, M, Z = (np.asarray(it[k]) for k in ("C", "M", "Z"))
+            r1[b], r2[b] = M.shape
+            Cp[b], Mp[b], Zp[b] = dev(Cm), dev(M), dev(Z)
+            ldc[b], ldm[b], ldz[b] = nb, max(M.shape[0], 1), max(M.shape[1], 1)
+        first, _, leaf = it["cl"] if it.get("cl") is not None else (0, nb, leafsize)
+        o = _lib.hs_hss_options(leaf, first, atol, rtol, kest, pad, seed + b, level_scale)
+        opts.append(o)
+        op[b] = C.pointer(o)
+        if it.get("perm") is not None:
+            q = np.ascontiguousarray(it["perm"], dtype=np.int64)
+            perms.append(q)
+            pp[b] = q.ctypes.data_as(_lib.p_i64)
+    out = (C.c_void_p * cnt)()
+    L = _lib.lib()
+    f = L.hs_hss_compress_lru_multi_z if is_c else L.hs_hss_compress_lru_multi_d
+    _lib.check(f(cnt, n, Bp, ldb, Cp, ldc, Mp, ldm, Zp, ldz, r1, r2, pp, op, None, out))
+    torch.cuda.synchronize()
+    return [HssMatrix(C.c_void_p(out[b]), is_c) for b in range(cnt)]
+
+
 def randcompress_adaptive(A, cl=None, *, kest=64, **kw):
     """``randcompress_adaptive(A, cl, cl; kest, atol, rtol)`` (factorization.jl:110): the compression IS randomized and
     adaptive (samples double until every rank fits); ``kest`` is the initial number of samples."""

@@ -64,6 +64,17 @@ int hs_hss_compress_lru_d(int64_t n, const double* B, int64_t ldb, const double*
                           int64_t r1, int64_t r2, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
 int hs_hss_compress_lru_z(int64_t n, const double* B, int64_t ldb, const double* C, int64_t ldc, const double* M, int64_t ldm, const double* Z, int64_t ldz,
                           int64_t r1, int64_t r2, int where, const int64_t* perm, const hs_hss_options* o, void* stream, hs_hss** out);
+/* The same for `count` matrices at once (all operands on the DEVICE): B[b] - C[b]*M[b]*Z[b] (r1[b] = 0: no update; M[b] = NULL with r1 = r2: the
+   identity), perm[b] on the host or NULL, one options block per matrix (leafsize, first_split, seed, kest are its own; atol, rtol, pad,
+   level_scale those of opts[0]; the sample count is common).  The compressions of the Schur complements of one tree level are independent
+   chains of small dependent launches: batched, a stage of a cluster-tree level is ONE group of launches for all of them.  out[b] share the
+   generators of one forest, which lives until the last of them is freed. */
+int hs_hss_compress_lru_multi_d(int64_t count, const int64_t* n, const double* const* B, const int64_t* ldb, const double* const* C, const int64_t* ldc,
+                                const double* const* M, const int64_t* ldm, const double* const* Z, const int64_t* ldz, const int64_t* r1, const int64_t* r2,
+                                const int64_t* const* perm, const hs_hss_options* const* opts, void* stream, hs_hss** out);
+int hs_hss_compress_lru_multi_z(int64_t count, const int64_t* n, const double* const* B, const int64_t* ldb, const double* const* C, const int64_t* ldc,
+                                const double* const* M, const int64_t* ldm, const double* const* Z, const int64_t* ldz, const int64_t* r1, const int64_t* r2,
+                                const int64_t* const* perm, const hs_hss_options* const* opts, void* stream, hs_hss** out);
 
 /* later products / eliminations / solves run on `stream` (hipStream_t; NULL = the default stream); every call still returns only after its
  * work on that stream has completed */

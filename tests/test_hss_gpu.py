@@ -351,3 +351,47 @@ def test_expand_equals_products_with_the_identity(hs, dtype):
         assert np.linalg.norm(V.expand() - F[sl, sl]) / np.linalg.norm(F[sl, sl]) < 1e-12
     Hl = hs.hss.compress(K[:40, :40], leafsize=64, atol=1e-9, rtol=1e-9, kest=16)  # a single leaf
     assert np.allclose(Hl.expand(), K[:40, :40])
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_batched_compression_of_several_operators(hs, complex_):
+    """hs_hss_compress_lru_multi: matrices of different sizes, one permuted, one with a low-rank update, one with a forced first split, compressed
+    as ONE forest -- every result represents its own operator to the tolerance, with the rank of the one-at-a-time compression."""
+    rng = np.random.default_rng(11)
+    items, refs = [], []
+    for b, n in enumerate((520, 700, 380)):
+        K = kernel_matrix(n, complex_, seed=20 + b)
+        it = dict(B=K)
+        A = K
+        if b == 0:  # scrambled: perm restores the order the kernel compresses in
+            q = rng.permutation(n)
+            inv = np.argsort(q)
+            it = dict(B=K[np.ix_(inv, inv)], perm=q)
+            A = it["B"]
+        if b == 1:  # B - C*M*Z with smooth factors
+            r = 7
+            Cm = np.cos(np.outer(np.linspace(0, 1, n), np.arange(1, r + 1)))
+            Z = np.sin(np.outer(np.arange(1, r + 1), np.linspace(0, 2, n)))
+            M = rng.standard_normal((r, r))
+            it.update(C=Cm, M=M, Z=Z)
+            A = K - Cm @ M @ Z
+        if b == 2:
+            it["cl"] = (100, n, 48)
+        items.append(it)
+        refs.append(A)
+    Hs = hs.hss.compress_lowrank_update_batch(items, leafsize=48, atol=1e-9, rtol=1e-9, kest=32)
+    assert len(Hs) == 3
+    for it, A, H in zip(items, refs, Hs):
+        assert H.shape == A.shape
+        assert np.linalg.norm(H.full() - A) / np.linalg.norm(A) < 1e-6
+        b = rng.standard_normal(A.shape[0])
+        assert np.linalg.norm(H.ldiv(b) - np.linalg.solve(A, b)) / np.linalg.norm(b) < 1e-6
+        if it.get("C") is None:
+            H1 = hs.hss.compress(it["B"], it.get("cl"), leafsize=48, atol=1e-9, rtol=1e-9, kest=32, perm=it.get("perm"))
+        else:
+            H1 = hs.hss.compress_lowrank_update(it["B"], it["C"], it["M"], it["Z"], leafsize=48, atol=1e-9, rtol=1e-9, kest=32)
+        assert abs(H.rank - H1.rank) <= 6, (H.rank, H1.rank)
+    # the block views a parent front reads work on a matrix of a batch too
+    V = Hs[2].block(0)
+    assert V.shape == (100, 100)
+    assert np.linalg.norm(V.expand() - refs[2][:100, :100]) / np.linalg.norm(refs[2][:100, :100]) < 1e-6
