@@ -479,6 +479,10 @@ static void dmalloc(void** p, size_t bytes, const char* what);
 template <class T>
 static void mf_compress_schur_dense(hs_handle* h, int id, const T* SB, int lds, const T* C_, int ldc, const T* M, int ldm, const T* Z, int ldz, int r1, int r2,
                                     hipStream_t stream);
+template <class T>
+struct MfSchurArgs;
+template <class T>
+static void mf_compress_schur_dense_batch(hs_handle* h, const std::vector<MfSchurArgs<T>>& a, hipStream_t stream);
 template <class F>
 static void mf_parallel(hs_handle* h, int count, F&& body);
 #include "hs_compress.h"
@@ -994,11 +998,14 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
       std::vector<int> todo;
       for (int k = 0; k < L.ndense; ++k)
         if (h->nodes[L.mine[k]].s_hss) todo.push_back(L.mine[k]);
-      if (!todo.empty())
-        mf_parallel(h, (int)todo.size(), [&](int k, hipStream_t st) {
-          const NodeH& x = h->nodes[todo[k]];
-          mf_compress_schur_dense<T>(h, todo[k], x.ext_sb ? (const T*)x.ext_sb : dsb + x.off_SB, x.lds, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, st);
-        });
+      if (!todo.empty()) {
+        std::vector<MfSchurArgs<T>> args;
+        for (int id : todo) {
+          const NodeH& x = h->nodes[id];
+          args.push_back(MfSchurArgs<T>{id, x.ext_sb ? (const T*)x.ext_sb : dsb + x.off_SB, x.lds, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0});
+        }
+        mf_compress_schur_dense_batch<T>(h, args, s);
+      }
     }
     if (L.nmf > 0) factor_mf_fronts<T>(h, L.mine.data() + nb_, L.nmf);  // hs_mffront.h
     static const bool lvl_env = getenv("HS_VERBOSE_LEVELS") != nullptr;

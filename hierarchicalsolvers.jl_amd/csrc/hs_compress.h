@@ -150,9 +150,9 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
       if (W[i]) (void)hipFree(W[i]);
       if (W2[i]) (void)hipFree(W2[i]);
       if (W3[i]) (void)hipFree(W3[i]);
-      if (ZLo[i]) (void)hipFree(ZLo[i]);
+      hs_lr_free(ZLo[i]);
     }
-    for (void* p : tofree) (void)hipFree(p);
+    for (void* p : tofree) hs_lr_free(p);
     if (dgp) (void)hipFree(dgp);
   };
   try {
@@ -220,12 +220,12 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
           std::vector<int> todo;
           for (int i = 0; i < count; ++i)
             if (h->nodes[ids[i]].s_hss && W2[i]) todo.push_back(i);
-          if (!todo.empty())
-            mf_parallel(h, (int)todo.size(), [&](int t, hipStream_t st) {
-              const int i = todo[t];
-              const int ldw2 = (LL[i]->r + 1) / 2 * 2;
-              mf_compress_schur_dense<T>(h, ids[i], hd[i].SB, hd[i].lds, LL[i]->Cd, LL[i]->ldc, W2[i], ldw2, RR[i]->Z, RR[i]->ldz, LL[i]->r, RR[i]->r, st);
-            });
+          std::vector<MfSchurArgs<T>> args;
+          for (int i : todo) {
+            const int ldw2 = (LL[i]->r + 1) / 2 * 2;
+            args.push_back(MfSchurArgs<T>{ids[i], hd[i].SB, hd[i].lds, LL[i]->Cd, LL[i]->ldc, W2[i], ldw2, RR[i]->Z, RR[i]->ldz, LL[i]->r, RR[i]->r});
+          }
+          mf_compress_schur_dense_batch<T>(h, args, s);  // one batched compression for the fronts of the level (hs_mffront.h)
         }
         lap("S: HSS compression of the Schur operator");
       }
@@ -251,8 +251,8 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
       if (ZLo[i]) std::swap(LL[i]->Z, ZLo[i]);
       for (LowRank<T>* lr : {LL[i], RR[i]}) {  // the dense factor replaces the trapezoid form
         if (!lr->Cd) continue;
-        (void)hipFree(lr->Lp);
-        (void)hipFree(lr->rperm);
+        hs_lr_free(lr->Lp);
+        hs_lr_free(lr->rperm);
         lr->Lp = nullptr;
         lr->rperm = nullptr;
       }

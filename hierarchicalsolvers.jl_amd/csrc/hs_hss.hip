@@ -2197,8 +2197,8 @@ int lowrank_id_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, h
           hipLaunchKernelGGL(id_expand_kernel<T>, dim3((o.rows + 255) / 256), dim3(256), 0, s, (const int*)o.rperm, (const T*)qj[b].Tm, qj[b].ldt, o.rows, r, o.Cd, o.ldc);
         }
         // the packed LU and the sketch copy are not needed again
-        if (o.Lp) (void)hipFree(o.Lp);
-        if (o.Y0) (void)hipFree(o.Y0);
+        hs_lr_free(o.Lp);
+        hs_lr_free(o.Y0);
         o.Lp = nullptr;
         o.Y0 = nullptr;
       }

@@ -299,8 +299,8 @@ static void factor_hss_fronts(hs_handle* h, const int* ids, int count, const Nod
     for (int a = 0; a < nw; ++a)
       for (LowRank<T>* lr : {LL[a], RR[a]}) {  // the dense factor replaces the trapezoid form
         if (!lr->Cd) continue;
-        (void)hipFree(lr->Lp);
-        (void)hipFree(lr->rperm);
+        hs_lr_free(lr->Lp);
+        hs_lr_free(lr->rperm);
         lr->Lp = nullptr;
         lr->rperm = nullptr;
       }

@@ -3,6 +3,13 @@
 #include <cstdint>
 #include "hs_common.h"
 
+// Device blocks of the compressions (sketches, permutations, factors): recycled through a process-wide cache.  Every compression of a
+// block allocated and released a handful of them, and a hipFree synchronises the whole device: 16 blocks per tree level of an HSS
+// compression made the ALLOCATOR the cost of its pivoting stage, and serialised the host threads that compress fronts side by side.
+// hs_lr_free accepts any device pointer: one it did not hand out goes to hipFree.
+int hs_lr_alloc(void** out, size_t bytes);  // 0 on success (hipSuccess), else the hipError_t
+void hs_lr_free(void* p);
+
 template <class T>
 struct LowRank {
   T* Lp = nullptr;      // rows x k packed L\U of the pivoted sketch (ld = ldp); C = P' * unit-lower-trapezoid(Lp[:, :r])

@@ -17,6 +17,9 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "hs_sched.h"
@@ -59,13 +62,89 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ sr
 // ------------------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------------------
+namespace {
+struct LrCache {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_;
+  std::unordered_map<void*, size_t> live;
+  size_t held = 0;
+  static constexpr size_t limit = (size_t)16 << 30, max_block = (size_t)512 << 20;
+};
+LrCache* lr_cache() {
+  static LrCache* c = new LrCache();  // never destroyed: a static destructor would run after the HIP runtime has shut down
+  return c;
+}
+size_t lr_class(size_t bytes) {
+  size_t cls = 4096;
+  while (cls < bytes) cls <<= 1;
+  if (cls > 16384 && cls - cls / 4 >= bytes) cls -= cls / 4;
+  return cls;
+}
+}  // namespace
+int hs_lr_alloc(void** out, size_t bytes) {
+  *out = nullptr;
+  LrCache* c = lr_cache();
+  const bool cached = bytes <= LrCache::max_block;
+  const size_t cls = cached ? lr_class(bytes ? bytes : 256) : bytes;
+  if (cached) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->free_.find(cls);
+    if (it != c->free_.end()) {
+      *out = it->second;
+      c->free_.erase(it);
+      c->held -= cls;
+      c->live[*out] = cls;
+      return 0;
+    }
+  }
+  hipError_t e = hipMalloc(out, cls);
+  if (e != hipSuccess) {  // give the cached blocks back to the driver and try once more
+    (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      for (auto& kv : c->free_) (void)hipFree(kv.second);
+      c->free_.clear();
+      c->held = 0;
+    }
+    e = hipMalloc(out, cls);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      *out = nullptr;
+      return (int)e;
+    }
+  }
+  if (cached) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->live[*out] = cls;
+  }
+  return 0;
+}
+void hs_lr_free(void* p) {
+  if (!p) return;
+  LrCache* c = lr_cache();
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->live.find(p);
+    if (it != c->live.end()) {
+      const size_t cls = it->second;
+      c->live.erase(it);
+      if (c->held + cls <= LrCache::limit) {
+        c->free_.insert({cls, p});
+        c->held += cls;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+
 template <class T>
 void lowrank_free(LowRank<T>& lr) {
-  if (lr.Lp) (void)hipFree(lr.Lp);
-  if (lr.Z) (void)hipFree(lr.Z);
-  if (lr.rperm) (void)hipFree(lr.rperm);
-  if (lr.Cd) (void)hipFree(lr.Cd);
-  if (lr.Y0) (void)hipFree(lr.Y0);
+  hs_lr_free(lr.Lp);
+  hs_lr_free(lr.Z);
+  hs_lr_free(lr.rperm);
+  hs_lr_free(lr.Cd);
+  hs_lr_free(lr.Y0);
   lr = LowRank<T>();
 }
 

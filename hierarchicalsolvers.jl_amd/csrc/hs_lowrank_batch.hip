@@ -55,13 +55,12 @@ __global__ __launch_bounds__(256) void copy_top_rows_kernel(const T* __restrict_
 struct Guard {  // frees what it was given, whatever the exit path
   std::vector<void*> p;
   ~Guard() {
-    for (void* q : p)
-      if (q) (void)hipFree(q);
+    for (void* q : p) hs_lr_free(q);
   }
   template <class U>
   hipError_t alloc(U** out, size_t bytes) {
     *out = nullptr;
-    hipError_t e = hipMalloc((void**)out, bytes ? bytes : 256);
+    hipError_t e = (hipError_t)hs_lr_alloc((void**)out, bytes ? bytes : 256);
     if (e == hipSuccess) p.push_back(*out);
     return e;
   }
@@ -140,9 +139,8 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
     for (int a = 0; a < nj; ++a) {
       LowRankJob<T>& J = jobs[todo[a]];
       ldp[a] = (J.rows + 1) / 2 * 2;
-      if (hipMalloc((void**)&Y[a], sizeof(T) * ((size_t)ldp[a] * J.k + 32)) != hipSuccess) {
-        for (T* y : Y)
-          if (y) (void)hipFree(y);
+      if (hs_lr_alloc((void**)&Y[a], sizeof(T) * ((size_t)ldp[a] * J.k + 32)) != 0) {
+        for (T* y : Y) hs_lr_free(y);
         hs_set_error(-7, 0, "hipMalloc of a %d x %d sketch failed", J.rows, J.k);
         return -7;
       }
@@ -175,9 +173,9 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
     std::vector<T*> Y0(nj, nullptr);
     auto free_Y = [&]() {
       for (T* y : Y)
-        if (y) (void)hipFree(y);
+        hs_lr_free(y);
       for (T* y : Y0)
-        if (y) (void)hipFree(y);
+        hs_lr_free(y);
     };
     hipError_t e = hipMemcpyAsync(dn, hn.data(), sizeof(NodeDesc<T>) * nj, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(dgp, hgp.data(), sizeof(GemmProb<T>) * nj, hipMemcpyHostToDevice, s);
@@ -193,7 +191,7 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
       for (int a = 0; a < nj; ++a) {
         const LowRankJob<T>& J = jobs[todo[a]];
         const size_t el = (size_t)ldp[a] * J.k + 32;
-        if (hipMalloc((void**)&Y0[a], sizeof(T) * el) != hipSuccess) {
+        if (hs_lr_alloc((void**)&Y0[a], sizeof(T) * el) != 0) {
           free_Y();
           hs_set_error(-7, 0, "hipMalloc of a %d x %d sketch copy failed", J.rows, J.k);
           return -7;
@@ -230,9 +228,9 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
       if (!keep_sketch && r + 8 > J.k && J.k < kmax) {  // (with keep_sketch the caller judges the width from the refined rank)
         J.k = std::min(2 * J.k, kmax);
         next.push_back(todo[a]);
-        (void)hipFree(Y[a]);
+        hs_lr_free(Y[a]);
         Y[a] = nullptr;
-        if (Y0[a]) (void)hipFree(Y0[a]);
+        hs_lr_free(Y0[a]);
         Y0[a] = nullptr;
         hn[a].mcols[1] = 0;  // takes no part in the second phase of this pass
         hn[a].mrows[1] = 0;
@@ -261,8 +259,8 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
         LowRank<T>& o = *J.out;
         const int r = rank[a];
         o.ldz = std::max(2, (r + 1) / 2 * 2);
-        if ((need_z && hipMalloc((void**)&o.Z, sizeof(T) * ((size_t)o.ldz * J.cols + 32)) != hipSuccess) ||
-            hipMalloc((void**)&o.rperm, sizeof(int) * J.rows) != hipSuccess) {
+        if ((need_z && hs_lr_alloc((void**)&o.Z, sizeof(T) * ((size_t)o.ldz * J.cols + 32)) != 0) ||
+            hs_lr_alloc((void**)&o.rperm, sizeof(int) * J.rows) != 0) {
           free_Y();
           hs_set_error(-7, 0, "hipMalloc of a low-rank factor (%d x %d) failed", r, J.cols);
           return -7;

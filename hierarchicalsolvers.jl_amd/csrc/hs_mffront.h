@@ -252,6 +252,78 @@ static void mf_compress_schur_dense(hs_handle* h, int id, const T* SB, int lds, 
   if (h->opts.verbose) fprintf(stderr, "[hs] node %d (level %d, nb=%d): hssrank(S)=%lld (%lld samples)\n", id, x.level, x.nb, (long long)hs_hss_rank(H), (long long)hs_hss_samples(H));
 }
 
+// The same for several fronts of one level at once: ONE batched compression (hs_hss_compress_lru_multi) -- compressed one at a time each is a
+// chain of ~10,000 small dependent launches (110 ms for nb = 12,097; the eight transition fronts of Poisson 128^3: 641 ms with two at a time).
+template <class T>
+struct MfSchurArgs {
+  int id;
+  const T* SB; int lds;
+  const T* C; int ldc;
+  const T* M; int ldm;
+  const T* Z; int ldz;
+  int r1, r2;
+};
+template <class T>
+static void mf_compress_schur_dense_group(hs_handle* h, const std::vector<MfSchurArgs<T>>& a, hipStream_t stream);
+template <class T>
+static void mf_compress_schur_dense_batch(hs_handle* h, const std::vector<MfSchurArgs<T>>& a, hipStream_t stream) {
+  static const bool batch_on = getenv("HS_MF_BATCH") && getenv("HS_MF_BATCH")[0] == '1';  // off by default: measured no faster than one compression per host thread
+  const int cnt = (int)a.size();
+  if (cnt == 0) return;
+  if (cnt == 1 || !batch_on) {
+    mf_parallel(h, cnt, [&](int t, hipStream_t st) {
+      const MfSchurArgs<T>& q = a[t];
+      mf_compress_schur_dense<T>(h, q.id, q.SB, q.lds, q.C, q.ldc, q.M, q.ldm, q.Z, q.ldz, q.r1, q.r2, st);
+    });
+    return;
+  }
+  // a single chain leaves the chip idle at every host round trip (rank decisions): two or more forests side by side fill each other's gaps
+  static const int groups_env = getenv("HS_MF_BATCH_GROUPS") ? atoi(getenv("HS_MF_BATCH_GROUPS")) : 2;
+  const int groups = std::max(1, std::min(groups_env, cnt / 2));
+  if (groups > 1) {
+    std::vector<std::vector<MfSchurArgs<T>>> part((size_t)groups);
+    for (int t = 0; t < cnt; ++t) part[(size_t)(t % groups)].push_back(a[t]);
+    mf_parallel(h, groups, [&](int g, hipStream_t st) { mf_compress_schur_dense_group<T>(h, part[(size_t)g], st); });
+    return;
+  }
+  mf_compress_schur_dense_group<T>(h, a, stream);
+}
+template <class T>
+static void mf_compress_schur_dense_group(hs_handle* h, const std::vector<MfSchurArgs<T>>& a, hipStream_t stream) {
+  const int cnt = (int)a.size();
+  HS_HIP(hipStreamSynchronize(h->stream));
+  std::vector<int64_t> n(cnt), ldb(cnt), ldc(cnt), ldm(cnt), ldz(cnt), r1(cnt), r2(cnt);
+  std::vector<const double*> B(cnt), Cp(cnt), Mp(cnt), Zp(cnt);
+  std::vector<const int64_t*> perm(cnt);
+  std::vector<hs_hss_options> opt(cnt);
+  std::vector<const hs_hss_options*> po(cnt);
+  std::vector<hs_hss*> out(cnt, nullptr);
+  for (int t = 0; t < cnt; ++t) {
+    const MfSchurArgs<T>& q = a[t];
+    NodeH& x = h->nodes[q.id];
+    const int64_t fs = (x.n1p > 0 && x.n1p < x.nb) ? x.n1p : 0;
+    opt[t] = mf_options(h, q.id, 1.0, fs, x.last_ks, x.nb);
+    po[t] = &opt[t];
+    n[t] = x.nb; B[t] = (const double*)q.SB; ldb[t] = q.lds;
+    Cp[t] = (const double*)q.C; ldc[t] = q.ldc; Mp[t] = (const double*)q.M; ldm[t] = q.ldm; Zp[t] = (const double*)q.Z; ldz[t] = q.ldz;
+    r1[t] = (q.C && q.M && q.Z) ? q.r1 : 0; r2[t] = (q.C && q.M && q.Z) ? q.r2 : 0;
+    perm[t] = x.sperm.data();
+  }
+  const int st = h->is_complex ? hs_hss_compress_lru_multi_z(cnt, n.data(), B.data(), ldb.data(), Cp.data(), ldc.data(), Mp.data(), ldm.data(), Zp.data(), ldz.data(), r1.data(),
+                                                             r2.data(), perm.data(), po.data(), (void*)stream, out.data())
+                               : hs_hss_compress_lru_multi_d(cnt, n.data(), B.data(), ldb.data(), Cp.data(), ldc.data(), Mp.data(), ldm.data(), Zp.data(), ldz.data(), r1.data(),
+                                                             r2.data(), perm.data(), po.data(), (void*)stream, out.data());
+  mf_check(st);
+  for (int t = 0; t < cnt; ++t) {
+    NodeH& x = h->nodes[a[t].id];
+    x.S_hss = out[t];
+    x.last_ks = (int)hs_hss_samples(out[t]);
+    mf_maxrank(h, hs_hss_rank(out[t]));
+    if (h->opts.verbose)
+      fprintf(stderr, "[hs] node %d (level %d, nb=%d): hssrank(S)=%lld (%lld samples, batch of %d)\n", a[t].id, x.level, x.nb, (long long)hs_hss_rank(out[t]), (long long)hs_hss_samples(out[t]), cnt);
+  }
+}
+
 // the blocks of one child's Schur complement a parent reads (factorization.jl:127-135): S.A11 / S.A22 as views sharing the generators
 struct MfChild {
   hs_hss* S = nullptr;
