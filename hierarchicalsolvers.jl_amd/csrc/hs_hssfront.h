@@ -347,8 +347,10 @@ static void hss_d_solve(hs_handle* h, const NodeH& x, T* B, int ldb, int q, hipS
   const int kmax = std::max(std::max(k12, k21), 1), ldt = (kmax + 1) / 2 * 2;
   T* t = nullptr;
   GemmProb<T>* dgp = nullptr;
-  dmalloc((void**)&t, ((size_t)ldt * q + 32) * sizeof(T), "block-solve scratch");
-  dmalloc((void**)&dgp, 2 * sizeof(GemmProb<T>), "GEMM descriptors");
+  if (hs_lr_alloc((void**)&t, ((size_t)ldt * q + 32) * sizeof(T)) != 0 || hs_lr_alloc((void**)&dgp, 2 * sizeof(GemmProb<T>)) != 0) {
+    hs_lr_free(t);
+    HS_FAIL(HS_ERR_NOMEM, 0, "hipMalloc of the block-solve scratch failed");
+  }
   auto pair = [&](const T* Z, int ldz, int k, int cols, const T* X, const T* C, int ldc, int rows, T* Y) {  // Y -= C * (Z * X)
     if (k <= 0) return;
     GemmProb<T> gp[2] = {GemmProb<T>{Z, X, t, k, q, cols, ldz, ldb, ldt}, GemmProb<T>{C, t, Y, rows, q, k, ldc, ldt, ldb}};
@@ -364,12 +366,12 @@ static void hss_d_solve(hs_handle* h, const NodeH& x, T* B, int ldb, int q, hipS
     HS_HIP(hipStreamSynchronize(s));
   } catch (...) {
     (void)hipStreamSynchronize(s);
-    (void)hipFree(t);
-    (void)hipFree(dgp);
+    hs_lr_free(t);
+    hs_lr_free(dgp);
     throw;
   }
-  (void)hipFree(t);
-  (void)hipFree(dgp);
+  hs_lr_free(t);
+  hs_lr_free(dgp);
 }
 
 // forward sweep of level lv:  t = H^-1 rhs[int];  rhs[bnd] -= C_L * (Z_L * t)

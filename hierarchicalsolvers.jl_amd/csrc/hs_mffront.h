@@ -358,21 +358,18 @@ struct MfChild {
 };
 
 template <class T>
-struct MfBuf {  // device buffers of one front's elimination, freed on every exit path
+struct MfBuf {  // device buffers of one front's elimination, released on every exit path (recycled blocks: a hipFree would synchronise the
+                // device under the other fronts that are being compressed)
   std::vector<void*> p;
   ~MfBuf() {
-    for (void* q : p)
-      if (q) (void)hipFree(q);
+    for (void* q : p) hs_lr_free(q);
   }
   T* get(size_t elems, const char* what) {
     void* q = nullptr;
-    dmalloc(&q, (elems + 32) * sizeof(T), what);
+    const size_t bytes = (elems + 32) * sizeof(T);
+    if (hs_lr_alloc(&q, bytes) != 0) HS_FAIL(HS_ERR_NOMEM, 0, "hipMalloc of %.3f GiB for %s failed", bytes / 1073741824.0, what);
     p.push_back(q);
     return (T*)q;
-  }
-  void release(void* q) {  // ownership moves to the caller
-    for (auto& e : p)
-      if (e == q) e = nullptr;
   }
 };
 
