@@ -520,9 +520,25 @@ void run_gemms(Pool& tmp, std::vector<GemmProb<T>>& probs, int minus, hipStream_
     return;
   }
   GemmProb<T>* d = upload(tmp, live, s);
+  static const bool glog = getenv("HS_HSS_GEMM_LOG") != nullptr;  // diagnostics: wall time of every grouped product (adds synchronisations)
+  std::chrono::steady_clock::time_point t0;
+  if (glog) {
+    (void)hipStreamSynchronize(s);
+    t0 = std::chrono::steady_clock::now();
+  }
   for (size_t b = 0; b < live.size(); b += 32768) {
     const int cnt = (int)std::min<size_t>(32768, live.size() - b);
     launch_gemm_probs<T>(d + b, cnt, mM, mN, minus, s);
+  }
+  if (glog) {
+    (void)hipStreamSynchronize(s);
+    int mK = 0;
+    double fl = 0;
+    for (auto& q : live) {
+      mK = std::max(mK, q.K);
+      fl += 2.0 * q.M * q.N * q.K;
+    }
+    fprintf(stderr, "[hs gemm] %zu problems maxM %d maxN %d maxK %d flops %.3g  %.1f us\n", live.size(), mM, mN, mK, fl, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
   }
 }
 

@@ -273,6 +273,135 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
 }
 
 // ------------------------------------------------------------------------------------------------
+// real double, SKINNY problems (the grouped products of the HSS module: a 64-row window against 2,048 sample columns, 64 x 64 Gram
+// matrices over a long inner dimension, ...).  The same pipeline with a 64 x 128 or 64 x 64 tile: a lone workgroup pays 64 MFMAs per wave and
+// K-step of the 128 x 128 tile (1.7 us) whether its rows exist or not -- half or three quarters of them multiply padding when M, N <= 64 --
+// and these launches are latency chains of K/16 such steps, not throughput.  2 x 2 waves, wave tile (BMs/2) x (BNs/2).
+// ------------------------------------------------------------------------------------------------
+template <int BMs, int BNs>
+__device__ inline void gemm_tile_s_d(const GemmProb<double>& p, int tile_m, int tile_n, bool minus, double* smem) {
+  constexpr int STAGE = 2 * BK * LDS_LD;
+  constexpr int WM = BMs / 2, WN = BNs / 2, MI = WM / 16, NJ = WN / 16;
+  constexpr int NP = BMs / 2, KA = 256 / NP, PA = BK / KA;  // A staging: row pairs, k rows per pass, passes
+  constexpr int PB = BNs / 32;                               // B staging passes
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = tile_m * BMs, n0 = tile_n * BNs;
+  const int M = p.M, N = p.N, K = p.K;
+  const double* __restrict__ A = p.A;
+  const double* __restrict__ B = p.B;
+  const int a_pair = tid % NP, a_k = tid / NP;
+  const int b_kp = tid & 7, b_n = tid >> 3;
+  double2_u ra[PA], rb[PB];
+  const bool interior = (m0 + BMs <= M) && (n0 + BNs <= N);
+  auto load_tile = [&](int k0) {
+    if (interior && k0 + BK <= K) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = gld2(A + (size_t)(m0 + 2 * a_pair) + (size_t)(k0 + a_k + KA * i) * p.lda);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb[i] = gld2(B + (size_t)(k0 + 2 * b_kp) + (size_t)(n0 + b_n + 32 * i) * p.ldb);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int kk = k0 + a_k + KA * i, mm = m0 + 2 * a_pair;
+        const double* col = A + (size_t)min(kk, K - 1) * p.lda;
+        double x = gld(col + min(mm, M - 1)), y = gld(col + min(mm + 1, M - 1));
+        const bool kok = kk < K;
+        ra[i].x = (kok && mm < M) ? x : 0.0;
+        ra[i].y = (kok && mm + 1 < M) ? y : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int nn = n0 + b_n + 32 * i, kk = k0 + 2 * b_kp;
+        const double* col = B + (size_t)min(nn, N - 1) * p.ldb;
+        double x = gld(col + min(kk, K - 1)), y = gld(col + min(kk + 1, K - 1));
+        const bool nok = nn < N;
+        rb[i].x = (nok && kk < K) ? x : 0.0;
+        rb[i].y = (nok && kk + 1 < K) ? y : 0.0;
+      }
+    }
+  };
+  auto store_tile = [&](int stage) {
+    double* As = smem + stage * STAGE;
+    double* Bs = As + BK * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      double* dst = As + (a_k + KA * i) * LDS_LD + 2 * a_pair;
+      dst[0] = ra[i].x;
+      dst[1] = ra[i].y;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      double* dst = Bs + (b_n + 32 * i) * LDB_S + 2 * b_kp;
+      dst[0] = rb[i].x;
+      dst[1] = rb[i].y;
+    }
+  };
+  double4_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int a_off = l4 * LDS_LD + wm * WM + l15;
+  const int b_off = BK * LDS_LD + (wn * WN + l15) * LDB_S + l4;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool more = (k0 + BK) < K;
+    if (more) load_tile(k0 + BK);
+    const double* a_rd = smem + cur * STAGE + a_off;
+    const double* b_rd = smem + cur * STAGE + b_off;
+    {
+      double bf[NJ][BK / 4], af[MI][BK / 4];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) bf[j][ks] = b_rd[(j * 16) * LDB_S + ks * 4];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) af[i][ks] = a_rd[(ks * 4) * LDS_LD + i * 16];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int ks = 0; ks < BK / 4; ++ks) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  double* __restrict__ C = p.C;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int mm = m0 + wm * WM + i * 16 + l15;
+    const bool rok = mm < M;
+    double cv[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n0 + wn * WN + j * 16 + l4 + 4 * r;
+        cv[j][r] = (minus && rok && nn < N) ? gld(C + (size_t)mm + (size_t)nn * p.ldc) : 0.0;
+      }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n0 + wn * WN + j * 16 + l4 + 4 * r;
+        if (rok && nn < N) gst(C + (size_t)mm + (size_t)nn * p.ldc, minus ? (cv[j][r] - acc[i][j][r]) : acc[i][j][r]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // complex double (planar split in LDS)
 // ------------------------------------------------------------------------------------------------
 #define ZBN 64
@@ -479,6 +608,27 @@ __global__ __launch_bounds__(256, 2) void gemm_probs_kernel(const GemmProb<T>* _
   if (p.M <= 0 || p.N <= 0) return;
   gemm_dispatch<T>(p, minus != 0, smem);
 }
+// Problem lists that cannot fill the chip with 128 x 128 tiles (launch_gemm_probs decides): what such a launch costs is the LENGTH of a
+// tile's K loop (1.7 us per 16 columns for a lone workgroup), so the work is cut into 64 x 64 tiles -- a quarter of the MFMAs per K-step,
+// four times the workgroups -- and 64 x 128 for a problem with M <= 64 < N.
+__global__ __launch_bounds__(256, 2) void gemm_probs_skinny_kernel(const GemmProb<double>* __restrict__ probs, int minus) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  GemmProb<double> p = probs[blockIdx.y];
+  if (p.M <= 0 || p.N <= 0) return;
+  if (p.M <= 64 && p.N > 64) {
+    const int tn_ = (p.N + 127) / 128;
+    for (int bid = blockIdx.x; bid < tn_; bid += gridDim.x) {
+      gemm_tile_s_d<64, 128>(p, 0, bid, minus != 0, smem);
+      if (bid + (int)gridDim.x < tn_) __syncthreads();
+    }
+    return;
+  }
+  const int tm_ = (p.M + 63) / 64, tn_ = (p.N + 63) / 64, nt = tm_ * tn_;
+  for (int bid = blockIdx.x; bid < nt; bid += gridDim.x) {
+    gemm_tile_s_d<64, 64>(p, bid % tm_, bid / tm_, minus != 0, smem);
+    if (bid + (int)gridDim.x < nt) __syncthreads();
+  }
+}
 
 
 template <class T>
@@ -544,6 +694,20 @@ void launch_gemm_probs(const GemmProb<T>* dprobs, int nprob, int maxM, int maxN,
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_probs_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
+  }
+  if constexpr (sizeof(T) == 8) {
+    static const bool skinny = !(getenv("HS_GEMM_SKINNY") && getenv("HS_GEMM_SKINNY")[0] == '0');
+    static const int small_tiles = getenv("HS_GEMM_SMALL_TILES") ? atoi(getenv("HS_GEMM_SMALL_TILES")) : 128;  // lists of at most this many 128 x 128 tiles
+    if (skinny && (maxM <= 64 || (long long)tiles * nprob <= small_tiles)) {
+      if (maxM > 64) tiles = ((maxM + 63) / 64) * ((maxN + 63) / 64);
+      static bool attr_set_s = false;
+      if (!attr_set_s) {
+        (void)hipFuncSetAttribute((const void*)gemm_probs_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set_s = true;
+      }
+      hipLaunchKernelGGL(gemm_probs_skinny_kernel, dim3(tiles, nprob), dim3(256), lds_bytes, s, (const GemmProb<double>*)dprobs, minus);
+      return;
+    }
   }
   hipLaunchKernelGGL(gemm_probs_kernel<T>, dim3(tiles, nprob), dim3(256), lds_bytes, s, dprobs, minus);
 }

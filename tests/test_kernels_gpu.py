@@ -49,6 +49,13 @@ def test_gemm_shapes(hs, M, N, K, cplx):
     run_gemm(hs, M, N, K, cplx, minus=False, pad=(0, 0, 0), seed=M * 3 + K)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 64, 2048), (64, 2048, 500), (40, 50, 1000), (64, 700, 333), (33, 129, 17), (1, 64, 64), (64, 65, 16), (7, 300, 4100)])
+def test_gemm_skinny_tiles(hs, M, N, K):
+    """Problem lists whose M <= 64 run the 64 x 64 / 64 x 128 tiles (gemm_probs_skinny_kernel): the grouped products of the HSS module."""
+    run_gemm(hs, M, N, K, False, minus=True, pad=(2, 3, 1), seed=M + N + K)
+    run_gemm(hs, M, N, K, False, minus=False, pad=(0, 0, 0), seed=M * 3 + K)
+
+
 def test_gemm_mfma_layout_asymmetric(hs):
     """A = I with an asymmetric B exposes a transposed / permuted C write (cdna guide section 3)."""
     n = 128
