@@ -1670,11 +1670,12 @@ static void hss_bases_impl(HssT<T>& H, Pool& tmp, int node, T* out, int ldo, std
       if (x.left < 0) {
         if (x.hinvp.empty()) {
           std::vector<int> hp(x.m);
-          HSS_HIP(hipMemcpy(hp.data(), x.p, sizeof(int) * x.m, hipMemcpyDeviceToHost));
+          HSS_HIP(hipMemcpyAsync(hp.data(), x.p, sizeof(int) * x.m, hipMemcpyDeviceToHost, s));
+          HSS_HIP(hipStreamSynchronize(s));
           x.hinvp.assign(x.m, 0);
           for (int a = 0; a < x.m; ++a) x.hinvp[hp[a]] = a;
         }
-        int* dip = upload(tmp, x.hinvp);
+        int* dip = upload(tmp, x.hinvp, s);
         bj.push_back(BasisJob<T>{x.Tm, x.ldt, rk, cnt, dip, E[i], lde[i], 0});
         maxcnt = std::max(maxcnt, cnt);
         maxr = std::max(maxr, rk);
@@ -1697,7 +1698,7 @@ static void hss_bases_impl(HssT<T>& H, Pool& tmp, int node, T* out, int ldo, std
       }
     }
     if (!bj.empty()) {
-      BasisJob<T>* dj = upload(tmp, bj);
+      BasisJob<T>* dj = upload(tmp, bj, s);
       hipLaunchKernelGGL(basis_rows_kernel<T>, dim3((maxcnt + 63) / 64, (maxr + 15) / 16, (unsigned)bj.size()), dim3(64), 0, s, (const BasisJob<T>*)dj);
     }
     run_rows(tmp, neg, s);
@@ -1776,7 +1777,7 @@ void hss_expand(HssT<T>& H, T* out, int ldo) {
 // elimination
 // ------------------------------------------------------------------------------------------------
 template <class T>
-void alloc_front(Pool& pool, NodeDesc<T>& d, int ni, int nb, int node) {
+void alloc_front(Pool& pool, NodeDesc<T>& d, int ni, int nb, int node, hipStream_t s) {
   memset(&d, 0, sizeof d);
   const int m = ni + nb, nblk = (ni + HS_PB - 1) / HS_PB, ncand = ((ni + 127) / 128 + 1) * HS_PB;
   d.ldl = ev(m);
@@ -1788,7 +1789,9 @@ void alloc_front(Pool& pool, NodeDesc<T>& d, int ni, int nb, int node) {
   d.invL = pool.get<T>((size_t)2 * std::max(nblk, 1) * HS_PB * HS_PB);
   d.invU = d.invL + (size_t)std::max(nblk, 1) * HS_PB * HS_PB;
   int* ints = pool.get<int>((size_t)2 * ni + 2 * ncand + HS_PB + 8);
-  HSS_HIP(hipMemset(ints, 0, sizeof(int) * ((size_t)2 * ni + 2 * ncand + HS_PB + 8)));
+  // (on the caller's stream: a synchronous memset runs on the null stream, which waits for -- and holds up -- every blocking stream of the process,
+  // i.e. the other fronts that are being compressed on their own host threads)
+  HSS_HIP(hipMemsetAsync(ints, 0, sizeof(int) * ((size_t)2 * ni + 2 * ncand + HS_PB + 8), s));
   d.ipiv = ints;
   d.rperm = d.ipiv + ni;
   d.cand0 = d.rperm + ni;
@@ -1827,7 +1830,7 @@ void hss_factor(HssT<T>& H) {
   std::vector<GemmProb<T>> gemms;
   auto t0 = std::chrono::steady_clock::now();
   auto finish_root = [&](const T* M, int ldm, int m) {
-    alloc_front(H.keep, H.rootfd, m, 0, 0);
+    alloc_front(H.keep, H.rootfd, m, 0, 0, s);
     subs.push_back(SubJob<T>{M, ldm, nullptr, nullptr, 0, 0, m, m, H.rootfd.LF, H.rootfd.ldl, 0});
     run_subs(tmp, subs, s);
     std::vector<NodeDesc<T>> one{H.rootfd};
@@ -1860,7 +1863,7 @@ void hss_factor(HssT<T>& H) {
       for (int i : L) {
         HNode<T>& x = nd[i];
         const int m = x.m, r = x.r, nR = m - r;
-        alloc_front(H.keep, x.fd, nR, r, i);
+        alloc_front(H.keep, x.fd, nR, r, i, s);
         x.has_front = nR > 0;
         const T* Ms = x.left < 0 ? x.D : M[i];
         const int ld = x.left < 0 ? x.ldd : ldm[i];
@@ -1893,14 +1896,14 @@ void hss_factor(HssT<T>& H) {
   std::vector<const NodeDesc<T>*> all{&H.rootfd};
   for (auto& x : nd)
     if (x.has_front) all.push_back(&x.fd);
-  for (const NodeDesc<T>* d : all) {
-    int info = 0;
-    HSS_HIP(hipMemcpy(&info, d->info, sizeof(int), hipMemcpyDeviceToHost));
-    if (info != 0) {
-      hs_set_error(HS_ERR_SINGULAR, d->node, "SingularException: HSS node %d hit an exactly zero pivot", d->node);
+  std::vector<int> infos(all.size(), 0);
+  for (size_t a = 0; a < all.size(); ++a) HSS_HIP(hipMemcpyAsync(&infos[a], all[a]->info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HSS_HIP(hipStreamSynchronize(s));
+  for (size_t a = 0; a < all.size(); ++a)
+    if (infos[a] != 0) {
+      hs_set_error(HS_ERR_SINGULAR, all[a]->node, "SingularException: HSS node %d hit an exactly zero pivot", all[a]->node);
       throw (int)HS_ERR_SINGULAR;
     }
-  }
   H.t_factor = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   H.factored = true;
 }
@@ -2081,7 +2084,8 @@ HssT<T>* compress_impl(int64_t n, const T* A, int64_t lda, int where, const hs_h
     for (int64_t i = 0; i < n; ++i) H->hinvperm[(size_t)hp[(size_t)i]] = (int)i;
     H->hperm = hp;
     H->perm = H->permpool.template get<int>((size_t)n);
-    HSS_HIP(hipMemcpy(H->perm, hp.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    HSS_HIP(hipMemcpyAsync(H->perm, hp.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, H->s));
+    HSS_HIP(hipStreamSynchronize(H->s));
   }
   Pool in(global_cache());
   const T* dA = A;
@@ -2775,7 +2779,8 @@ static void compress_multi_impl(int64_t count, const int64_t* n, const T* const*
         seen[(size_t)perm[b][i]] = 1;
         hp[(size_t)i] = (int)perm[b][i];
       }
-      HSS_HIP(hipMemcpy(dperm + off, hp.data(), sizeof(int) * (size_t)n[b], hipMemcpyHostToDevice));
+      HSS_HIP(hipMemcpyAsync(dperm + off, hp.data(), sizeof(int) * (size_t)n[b], hipMemcpyHostToDevice, H->s));
+      HSS_HIP(hipStreamSynchronize(H->s));
       B.perm = dperm + off;
       B.hperm = hp.data();
     }

@@ -233,7 +233,8 @@ void hss_getindex_batch(HssT<T>& H, const std::vector<GiJob<T>>& jobs) {
     if (!touched) continue;
     if (i != 0 && x.hinvp.empty()) {
       std::vector<int> hp(x.m);
-      HSS_HIP(hipMemcpy(hp.data(), x.p, sizeof(int) * x.m, hipMemcpyDeviceToHost));
+      HSS_HIP(hipMemcpyAsync(hp.data(), x.p, sizeof(int) * x.m, hipMemcpyDeviceToHost, s));
+      HSS_HIP(hipStreamSynchronize(s));
       x.hinvp.assign(x.m, 0);
       for (int a = 0; a < x.m; ++a) x.hinvp[hp[a]] = a;
     }
