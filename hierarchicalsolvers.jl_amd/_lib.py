@@ -75,7 +75,7 @@ EXPORTS = [
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned", "hs_gmres_d", "hs_gmres_z",
     "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_compress_lru_multi_d", "hs_hss_compress_lru_multi_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
-    "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_expand", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_free", "hs_node_schur_hss",
+    "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_expand", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_trim", "hs_hss_free", "hs_node_schur_hss",
     "hs_hss_offdiag", "hs_hss_bytes", "hs_hss_prune_leaves", "hs_hss_compatible", "hs_hss_depth", "hs_hss_compress_blockop_d", "hs_hss_compress_blockop_z", "hs_hss_blockop_apply",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_mfma_f64_peak_random", "hsk_bisect_perm",
 ]
@@ -227,6 +227,8 @@ def lib():
     L.hs_hss_node_data.restype = C.c_int
     L.hs_hss_getindex.argtypes = [vp, p_i64, i64, p_i64, i64, vp, i64, C.c_int]
     L.hs_hss_getindex.restype = C.c_int
+    L.hs_hss_trim.argtypes = []
+    L.hs_hss_trim.restype = i64
     L.hs_hss_basis.argtypes = [vp, i64, vp, i64, C.c_int]
     L.hs_hss_basis.restype = C.c_int
     L.hs_hss_expand.argtypes = [vp, vp, i64, C.c_int]

@@ -9,6 +9,7 @@
 // hs_lr_free accepts any device pointer: one it did not hand out goes to hipFree.
 int hs_lr_alloc(void** out, size_t bytes);  // 0 on success (hipSuccess), else the hipError_t
 void hs_lr_free(void* p);
+int64_t hs_lr_trim();  // releases the cached blocks to the driver; returns their bytes
 
 template <class T>
 struct LowRank {

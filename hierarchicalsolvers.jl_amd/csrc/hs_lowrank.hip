@@ -138,6 +138,19 @@ void hs_lr_free(void* p) {
   (void)hipFree(p);
 }
 
+int64_t hs_lr_trim() {
+  LrCache* c = lr_cache();
+  std::lock_guard<std::mutex> lk(c->mu);
+  int64_t freed = 0;
+  for (auto& kv : c->free_) {
+    (void)hipFree(kv.second);
+    freed += (int64_t)kv.first;
+  }
+  c->free_.clear();
+  c->held = 0;
+  return freed;
+}
+
 template <class T>
 void lowrank_free(LowRank<T>& lr) {
   hs_lr_free(lr.Lp);

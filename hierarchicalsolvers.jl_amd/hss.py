@@ -300,6 +300,11 @@ def compress_lowrank_update_batch(items, *, leafsize=64, atol=1e-6, rtol=1e-6, k
     return [HssMatrix(C.c_void_p(out[b]), is_c) for b in range(cnt)]
 
 
+def trim():
+    """Give the device blocks the library recycles between factorizations (up to 24 + 16 GiB) back to the driver; returns the bytes released."""
+    return int(_lib.lib().hs_hss_trim())
+
+
 def randcompress_adaptive(A, cl=None, *, kest=64, **kw):
     """``randcompress_adaptive(A, cl, cl; kest, atol, rtol)`` (factorization.jl:110): the compression IS randomized and
     adaptive (samples double until every rank fits); ``kest`` is the initial number of samples."""

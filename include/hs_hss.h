@@ -161,6 +161,9 @@ int hs_hss_factor(hs_hss* H);
 int hs_hss_ldiv(hs_hss* H, double* B, int64_t ldb, int64_t nrhs, int where);
 /* wall time of the last compress / factor on the device (seconds, host clock around a synchronised stream) */
 double hs_hss_time(const hs_hss* H, int what); /* 0: compress, 1: factor */
+/* The module recycles its device blocks (and those of the low-rank compressions of hs_factor_*) through process-wide caches, up to
+   24 + 16 GiB: hs_hss_trim gives them back to the driver and returns the device bytes released.  Call it with nothing in flight. */
+int64_t hs_hss_trim(void);
 
 /* `F.S` of one front of a factorization (include/hs_solver.h; needs hs_options.keep_schur) as an HSS matrix:
  * compress(S[perm,perm], cl, cl; atol, rtol), perm = [nd_loc.int; nd_loc.bnd], cl = bisection_cluster((|nd_loc.int|, |nd.bnd|))

@@ -395,3 +395,17 @@ def test_batched_compression_of_several_operators(hs, complex_):
     V = Hs[2].block(0)
     assert V.shape == (100, 100)
     assert np.linalg.norm(V.expand() - refs[2][:100, :100]) / np.linalg.norm(refs[2][:100, :100]) < 1e-6
+
+
+def test_trim_releases_the_recycled_blocks(hs):
+    """hs_hss_trim: the block caches hold memory between factorizations; trimming returns it and everything keeps working."""
+    K = kernel_matrix(600)
+    H = hs.hss.compress(K, leafsize=64, atol=1e-8, rtol=1e-8, kest=32)
+    b = np.arange(600.0)
+    x0 = H.ldiv(b)
+    freed = hs.hss.trim()
+    assert freed > 0
+    assert hs.hss.trim() == 0  # nothing left to give back
+    H2 = hs.hss.compress(K, leafsize=64, atol=1e-8, rtol=1e-8, kest=32)
+    assert np.allclose(H2.ldiv(b), x0, rtol=1e-6, atol=1e-9)
+    assert np.allclose(H.ldiv(b), x0)  # the generators a live matrix owns were never in the cache
