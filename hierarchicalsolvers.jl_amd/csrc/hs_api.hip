@@ -253,6 +253,7 @@ static void free_hss_any(hs_handle* h);
 static void free_mfd_buffers(hs_handle* h);
 static void free_handle(hs_handle* h) {
   if (!h) return;
+  if (h->stream) (void)hipStreamSynchronize(h->stream);  // recycled blocks must be idle when they go back to the caches
   for (auto& x : h->nodes)
     if (x.S_hss) {
       hs_hss_free((hs_hss*)x.S_hss);
@@ -917,6 +918,9 @@ template <class T>
 static void numeric_begin(hs_handle* h, const void* nzval, int on_device) {
   if (!nzval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: nzval == NULL");
   hipStream_t s = h->stream;
+  // the blocks released below are recycled, not returned to the driver (a hipFree would have waited for the device): nothing of the previous
+  // factorization -- a solve still in flight -- may be reading them when another stream takes them over
+  HS_HIP(hipStreamSynchronize(s));
   free_mfd_buffers(h);
   free_hss_nodes<T>(h);
   free_mf_nodes<T>(h);
