@@ -1137,7 +1137,7 @@ static void solve_bwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
     static const bool wide = !(getenv("HS_SOLVE_WIDE") && getenv("HS_SOLVE_WIDE")[0] == '0');
     if (wide) {
       const int nw = (L.maxni + hs_solve_wide_cols() - 1) / hs_solve_wide_cols();
-      for (int blk = nw - 1; blk >= 0; --blk) launch_bwd_wide<T>(dn, nb_, blk, w1, w2, s);
+      for (int blk = nw - 1; blk >= 0; --blk) launch_bwd_wide<T>(dn, nb_, blk, w1, w2, s, blk == nw - 1);
     } else {
       for (int blk = nblk - 1; blk >= 0; --blk) launch_bwd_step<T>(dn, nb_, blk, w1, w2, s);
     }

@@ -237,7 +237,7 @@ void launch_bwd_step(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hi
 template <class T>
 void launch_fwd_wide(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w, T* y, T* b, hipStream_t s);
 template <class T>
-void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s);
+void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s, bool first_call);  // first_call: the first step of the level's sweep
 template <class T>
 void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s, int only_block = -1);
 int hs_solve_wide_cols();

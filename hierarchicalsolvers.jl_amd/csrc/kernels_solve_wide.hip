@@ -153,7 +153,7 @@ __device__ __forceinline__ void wide_inv_partial(const T* iv, int row, int jg, i
 // forward: y_blk = L[blk,blk]^-1 * w_blk ; rows below -= L[:, blk] * y_blk   (rows >= ni are the Abi*U^-1 rows: they update rhs[bnd])
 template <class T>
 __global__ __launch_bounds__(1024) void fwd_wide_kernel(const SolveNode<T>* __restrict__ nodes, int blk, T* __restrict__ w, T* __restrict__ y,
-                                                        T* __restrict__ b) {
+                                                        T* __restrict__ b, int first_done) {
   const SolveNode<T> nd = nodes[blockIdx.y];
   const int c0 = blk * HS_SW;
   if (c0 >= nd.ni) return;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(1024) void fwd_wide_kernel(const SolveNode<T>* __re
       wold = b[gi];
     }
   }
-  if (blk > 0) {  // left behind by the previous step
+  if (blk > 0 || first_done) {  // left behind by the previous step (block 0: by wide_first_kernel)
     if (t < HS_SW) s_y[t] = (t < wl) ? y[nd.woff + c0 + t] : Scal<T>::zero();
   } else {
     if (t < HS_SW) s_w[t] = (t < wl) ? w[nd.woff + c0 + t] : Scal<T>::zero();
@@ -225,13 +225,13 @@ __global__ __launch_bounds__(1024) void fwd_wide_kernel(const SolveNode<T>* __re
 
 // backward: x_blk = U[blk,blk]^-1 * w_blk ; rows above -= U[:, blk] * x_blk
 template <class T>
-__global__ __launch_bounds__(1024) void bwd_wide_kernel(const SolveNode<T>* __restrict__ nodes, int blk, T* __restrict__ w, T* __restrict__ x) {
+__global__ __launch_bounds__(1024) void bwd_wide_kernel(const SolveNode<T>* __restrict__ nodes, int blk, T* __restrict__ w, T* __restrict__ x, int first_done) {
   const SolveNode<T> nd = nodes[blockIdx.y];
   const int c0 = blk * HS_SW;
   if (c0 >= nd.ni) return;
   const int wl = min(HS_SW, nd.ni - c0);
   if (blockIdx.x > 0 && (int)blockIdx.x * HS_SW >= c0) return;
-  const bool have_x = c0 + HS_SW < nd.ni;  // not the first step of this front's sweep: the step before left x_blk behind
+  const bool have_x = c0 + HS_SW < nd.ni || first_done;  // not the first step of this front's sweep: the step before left x_blk behind (the first: wide_first_kernel)
   if (have_x && c0 == 0) return;
   __shared__ T s_w[HS_SW];
   __shared__ T s_x[HS_SW];
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(1024) void bwd_wide_kernel(const SolveNode<T>* __re
   T wold = Scal<T>::zero();
   if (mine) wold = w[nd.woff + r];
   if (have_x) {
-    if (t < HS_SW) s_x[t] = x[nd.woff + c0 + t];
+    if (t < HS_SW) s_x[t] = (t < wl) ? x[nd.woff + c0 + t] : Scal<T>::zero();
   } else {
     if (t < HS_SW) s_w[t] = (t < wl) ? w[nd.woff + c0 + t] : Scal<T>::zero();
     __syncthreads();
@@ -284,6 +284,27 @@ __global__ __launch_bounds__(1024) void bwd_wide_kernel(const SolveNode<T>* __re
   if (t < HS_SW) x[nd.woff + c0 - HS_SW + t] = wide_sum<T>(s_red, t);
 }
 
+// the product of the FIRST block of a sweep with its stored inverse, once per front (forward: block 0, backward: the last block) -- inside the sweep
+// kernels every workgroup of the step would compute it again (16 workgroups per leaf front of Poisson 128^3)
+template <class T, bool LOWER>
+__global__ __launch_bounds__(1024) void wide_first_kernel(const SolveNode<T>* __restrict__ nodes, const T* __restrict__ w, T* __restrict__ out) {
+  const SolveNode<T> nd = nodes[blockIdx.x];
+  if (nd.ni <= 0) return;
+  const int blk = LOWER ? 0 : (nd.ni - 1) / HS_SW;
+  const int c0 = blk * HS_SW, wl = min(HS_SW, nd.ni - c0);
+  __shared__ T s_w[HS_SW];
+  __shared__ T s_red[HS_SW * WideCfg<T>::NG];
+  WIDE_COORDS;
+  (void)NG;
+  if (t < HS_SW) s_w[t] = (t < wl) ? w[nd.woff + c0 + t] : Scal<T>::zero();
+  __syncthreads();
+  T s[RP] = {};
+  wide_inv_partial<T, LOWER>((LOWER ? nd.inv256L : nd.inv256U) + (size_t)blk * HS_SW * HS_SW, row, jg, wl, s_w, s);
+  wide_put<T>(s_red, t, s);
+  __syncthreads();
+  if (t < wl) out[nd.woff + c0 + t] = wide_sum<T>(s_red, t);
+}
+
 template <class T>
 void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s, int only_block) {
   if (nbatch <= 0 || maxni <= 0) return;
@@ -303,14 +324,18 @@ void launch_fwd_wide(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w
   if (nbatch <= 0) return;
   const int rows = maxm - blk * HS_SW;
   const int gx = rows > 0 ? (rows + 255) / 256 : 1;
-  hipLaunchKernelGGL(fwd_wide_kernel<T>, dim3(gx, nbatch), dim3(1024), 0, s, dn, blk, w, y, b);
+  static const bool first = !(getenv("HS_SOLVE_FIRST") && getenv("HS_SOLVE_FIRST")[0] == '0');
+  if (first && blk == 0) hipLaunchKernelGGL((wide_first_kernel<T, true>), dim3(nbatch), dim3(1024), 0, s, dn, (const T*)w, y);
+  hipLaunchKernelGGL(fwd_wide_kernel<T>, dim3(gx, nbatch), dim3(1024), 0, s, dn, blk, w, y, b, first ? 1 : 0);
 }
 template <class T>
-void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s) {
+void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hipStream_t s, bool first_call) {
   if (nbatch <= 0) return;
   const int rows = blk * HS_SW;
   const int gx = rows > 0 ? (rows + 255) / 256 : 1;
-  hipLaunchKernelGGL(bwd_wide_kernel<T>, dim3(gx, nbatch), dim3(1024), 0, s, dn, blk, w, x);
+  static const bool first = !(getenv("HS_SOLVE_FIRST") && getenv("HS_SOLVE_FIRST")[0] == '0');
+  if (first && first_call) hipLaunchKernelGGL((wide_first_kernel<T, false>), dim3(nbatch), dim3(1024), 0, s, dn, (const T*)w, x);  // every front's own last block
+  hipLaunchKernelGGL(bwd_wide_kernel<T>, dim3(gx, nbatch), dim3(1024), 0, s, dn, blk, w, x, first ? 1 : 0);
 }
 int hs_solve_wide_cols() { return HS_SW; }
 
@@ -318,5 +343,5 @@ template void launch_inv256<double>(const SolveNode<double>*, int, int, hipStrea
 template void launch_inv256<cplx>(const SolveNode<cplx>*, int, int, hipStream_t, int);
 template void launch_fwd_wide<double>(const SolveNode<double>*, int, int, int, double*, double*, double*, hipStream_t);
 template void launch_fwd_wide<cplx>(const SolveNode<cplx>*, int, int, int, cplx*, cplx*, cplx*, hipStream_t);
-template void launch_bwd_wide<double>(const SolveNode<double>*, int, int, double*, double*, hipStream_t);
-template void launch_bwd_wide<cplx>(const SolveNode<cplx>*, int, int, cplx*, cplx*, hipStream_t);
+template void launch_bwd_wide<double>(const SolveNode<double>*, int, int, double*, double*, hipStream_t, bool);
+template void launch_bwd_wide<cplx>(const SolveNode<cplx>*, int, int, cplx*, cplx*, hipStream_t, bool);
