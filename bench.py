@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--hss-min", type=int, default=0, help="fronts of the compressed levels with at least this many interior DOFs (multiple of 1024) keep D = Aii as an HSS matrix; 0 = dense LU of D")
     ap.add_argument("--hss-dexp", type=int, default=None, help="orders of magnitude by which the HSS form of D is tighter than --tol (default 2)")
     ap.add_argument("--mf", nargs="?", const=1, default=0, type=int, help="matrix-free compressed branch: S travels between the compressed fronts as HSS matrices (the reference's data flow); 1 = interior blocks of those fronts dense (unless --hss-min), 2 = one HSS matrix, 3 = the reference's 2x2 block factorization over HSS blocks")
+    ap.add_argument("--dist-top", type=int, default=-1, help="N > 1: fronts above the rank cut eliminated by their whole group of ranks (csrc/hs_dist.h, RCCL inside the library); "
+                    "-1 = on for exact runs when the library's communicator passes its self-test on every rank, 0 = off (subtree-per-rank only: the group's first rank eliminates them)")
     ap.add_argument("--leafsize", type=int, default=32, help="SolverOptions.leafsize (HSS leaves; the device uses at least 128)")
     args = ap.parse_args()
 
@@ -240,8 +242,24 @@ def main():
     is_c = np.iscomplexobj(Ap.data)
 
     fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol, split_size=args.split, hss_min=args.hss_min, hss_dexp=args.hss_dexp, mf=args.mf, leafsize=args.leafsize) if args.swlevel != 0 else dict(swlevel=0)
+    libcomm, dist_note = None, None
+    if world > 1 and args.dist_top != 0 and args.swlevel == 0:
+        # the library's own communicator (RCCL over xGMI under the nccl process group): used only if its ring self-test passes on EVERY rank
+        ok = 1
+        try:
+            libcomm = hsdist.LibComm(rank, world, dev)
+            libcomm.selftest(1 << 22)
+        except Exception as e:  # noqa: BLE001
+            ok, dist_note = 0, f"rank {rank}: {e!r}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            fopts["dist_top"] = True
+        else:
+            libcomm = None
+            dist_note = dist_note or "the communicator self-test failed on another rank"
     t0 = time.perf_counter()
-    S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, **fopts)
+    S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, libcomm=libcomm, **fopts)
     torch.cuda.synchronize(dev)
     t_analyze = time.perf_counter() - t0  # hs_analyze: pattern upload, descriptors, hipMalloc of the factor arena (once per pattern)
     b_dev0 = torch.from_numpy(np.ascontiguousarray(bp)).to(dev)
@@ -294,7 +312,7 @@ def main():
         S.backend._h = None
         del S
         torch.cuda.empty_cache()
-        S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, profile=True, **fopts)
+        S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, profile=True, libcomm=libcomm, **fopts)
         S.numeric()
         sp_ = S.stats()
         if sp_["t_mfma_kernel"] > 0:
@@ -382,7 +400,7 @@ def main():
             "config": {"workload": args.workload, "n": int(Ap.shape[0]), "nnz": int(Ap.nnz), "tree_nodes": int(st["nnodes"]),
                        "tree_depth": int(st["nlevels"]), "max_front": [int(st["max_ni"]), int(st["max_nb"])], "nrhs": 1,
                        "compression": "none (swlevel=0)" if args.swlevel == 0 else f"{'matrix-free HSS hand-over' if args.mf else 'low-rank off-diagonal blocks'}, swlevel={args.swlevel} swsize={args.swsize} atol=rtol={args.tol:g} split={args.split} hss_min={args.hss_min} mf={int(args.mf)}",
-                       "partition": f"subtree-per-rank x{world}"},
+                       "partition": f"subtree-per-rank x{world}" + ((" + fronts above the cut over their rank groups (1-D block-cyclic block columns, " + libcomm.kind() + ")") if fopts.get("dist_top") else "")},
             "factor_s": st["t_total"],
             "residual": res,
             "maxrank": maxrank_main,
@@ -390,6 +408,8 @@ def main():
             "host_symbolic_s": t_host,
             "analyze_s": t_analyze,
         }
+        if dist_note:
+            out["dist_top_note"] = dist_note
         if flops:
             out["factor_tflops_minimal_count"] = flops / st["t_total"] / 1e12
         if world == 1 and t_ldiv > 0 and st["bytes_solve"] > 0:

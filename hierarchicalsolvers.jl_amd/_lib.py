@@ -23,7 +23,7 @@ class hs_options(C.Structure):
     _fields_ = [
         ("swlevel", i64), ("swsize", i64), ("atol", C.c_double), ("rtol", C.c_double), ("c_tol", C.c_double),
         ("leafsize", i64), ("kest", i64), ("stepsize", i64), ("verbose", C.c_uint8),
-        ("keep_schur", C.c_uint8), ("profile", C.c_uint8), ("split", C.c_uint8), ("hss_d", C.c_uint8), ("hss_dexp", C.c_uint8), ("mf", C.c_uint8), ("reserved", C.c_uint8 * 1), ("seed", i64),
+        ("keep_schur", C.c_uint8), ("profile", C.c_uint8), ("split", C.c_uint8), ("hss_d", C.c_uint8), ("hss_dexp", C.c_uint8), ("mf", C.c_uint8), ("dist_top", C.c_uint8), ("seed", i64),
     ]
 
 
@@ -60,6 +60,9 @@ class hs_hss_options(C.Structure):
                 ("level_scale", C.c_double)]
 
 
+# hs_transfer_fn (include/hs_solver.h): one host message per peer and direction
+HS_TRANSFER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, i64, p_i64, C.POINTER(C.c_void_p), p_i64, i64, p_i64, C.POINTER(C.c_void_p), p_i64)
+
 HS_OK = 0
 HS_ERR_ARGUMENT, HS_ERR_DIMENSION, HS_ERR_TREE, HS_ERR_SINGULAR = -1, -2, -3, -4
 HS_ERR_HSS_LEAF, HS_ERR_DEVICE, HS_ERR_NOMEM, HS_ERR_UNSUPPORTED = -5, -6, -7, -8
@@ -73,6 +76,7 @@ EXPORTS = [
     "hs_analyze", "hs_plan", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned", "hs_gmres_d", "hs_gmres_z",
+    "hs_comm_unique_id", "hs_comm_create_rccl", "hs_comm_create_host", "hs_comm_free", "hs_comm_kind", "hs_comm_selftest", "hs_set_comm",
     "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_compress_lru_multi_d", "hs_hss_compress_lru_multi_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_expand", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_trim", "hs_hss_free", "hs_node_schur_hss",
@@ -151,6 +155,20 @@ def lib():
     L.hs_unpack_bnd.restype = C.c_int
     L.hs_extract_owned.argtypes = [vp, vp, vp, vp]
     L.hs_extract_owned.restype = C.c_int
+    L.hs_comm_unique_id.argtypes = [vp]
+    L.hs_comm_unique_id.restype = C.c_int
+    L.hs_comm_create_rccl.argtypes = [vp, i64, i64, C.POINTER(vp)]
+    L.hs_comm_create_rccl.restype = C.c_int
+    L.hs_comm_create_host.argtypes = [HS_TRANSFER_FN, vp, i64, i64, C.POINTER(vp)]
+    L.hs_comm_create_host.restype = C.c_int
+    L.hs_comm_free.argtypes = [vp]
+    L.hs_comm_free.restype = None
+    L.hs_comm_kind.argtypes = [vp]
+    L.hs_comm_kind.restype = C.c_char_p
+    L.hs_comm_selftest.argtypes = [vp, i64]
+    L.hs_comm_selftest.restype = C.c_int
+    L.hs_set_comm.argtypes = [vp, vp]
+    L.hs_set_comm.restype = C.c_int
     for f in (L.hs_gmres_d, L.hs_gmres_z):
         f.argtypes = [vp, i64, p_i64, p_i64, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, i64, i64, p_f64, p_i64, C.POINTER(C.c_int), vp]
         f.restype = C.c_int

@@ -110,6 +110,8 @@ struct NodeH {
   int owner = 0;       // rank that eliminates this front
   bool mine = true;    // owner == my rank
   bool ghost = false;  // not mine, but one of my fronts absorbs its Schur complement (received from its owner)
+  int glo = 0, gcnt = 1;  // the ranks [glo, glo+gcnt) hold the subtrees below this node
+  bool dist = false;      // hs_options.dist_top: a front above the rank cut eliminated by its whole group (hs_dist.h); `mine` = member of the group
   int ldl = 0, ldu = 0, lds = 0;
   size_t off_LF = 0, off_UR = 0, off_SB = 0, off_inv = 0, off_inv256 = 0;        // element offsets
   size_t off_fidx = 0, off_ipiv = 0, off_rperm = 0, off_cmap = 0, off_cand = 0;  // int offsets
@@ -180,6 +182,7 @@ struct Exchange {
 
 #include "hs_sched.h"
 #include "hs_split.h"
+#include "hs_comm.h"
 
 struct hs_handle {
   bool is_complex = false;
@@ -233,6 +236,9 @@ struct hs_handle {
   hipStream_t stream_la = nullptr;  // CU-masked pair for the look-ahead schedule of a lone front: stream_la = every CU
   hipStream_t stream2m = nullptr;   // but a reserved few, stream2m = the reserved ones
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hs_comm* comm = nullptr;           // borrowed (hs_set_comm): moves everything that crosses ranks when hs_options.dist_top is set
+  hipStream_t stream_comm = nullptr; // every transfer is enqueued here
+  int* d_gflags = nullptr;           // nranks ints: flags agreed inside a group (hs_dist.h)
   Profiler prof;
   void* d_cdesc = nullptr;    // private descriptors (3 per front) of the compressed fronts being eliminated
   size_t cdesc_cap = 0;
@@ -269,6 +275,8 @@ static void free_handle(hs_handle* h) {
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->d_gflags) (void)hipFree(h->d_gflags);
+  if (h->stream_comm) (void)hipStreamDestroy(h->stream_comm);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream_la) (void)hipStreamDestroy(h->stream_la);
   if (h->stream2m) (void)hipStreamDestroy(h->stream2m);
@@ -437,7 +445,12 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr, const SplitTr
         cnt[x.left] = h->nranks;
       }
       x.owner = lo[i];
-      x.mine = (x.owner == h->rank);
+      x.glo = lo[i];
+      x.gcnt = x.level == 0 ? 1 : cnt[i];
+      x.dist = h->opts.dist_top && h->nranks > 1 && x.level >= 1 && cnt[i] > 1;
+      x.mine = x.dist ? (h->rank >= x.glo && h->rank < x.glo + x.gcnt) : (x.owner == h->rank);
+      if (x.level == 0 && h->opts.dist_top && h->nranks > 1)
+        HS_FAIL(HS_ERR_UNSUPPORTED, i, "hs_options.dist_top with a root that keeps a boundary (|root.bnd| = %d)", x.ni);
       if (!x.leaf && x.level >= 1) {
         if (x.right < 0) {  // later slice of a split front (single-rank plans only): same ranks as its only child
           lo[x.left] = lo[i];
@@ -457,7 +470,14 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr, const SplitTr
   h->exchanges.clear();
   for (int i = 0; i < h->nnodes; ++i) {
     NodeH& x = N[i];
-    if (x.parent >= 0 && N[x.parent].owner != x.owner) {
+    if (x.parent >= 0 && N[x.parent].dist) {
+      // the parent is eliminated by the union of the two children's groups: every rank of this node's group swaps with its partner in the
+      // sibling's group (rank +- gcnt), so that each member of the parent's group holds both Schur complements
+      const NodeH& p = N[x.parent];
+      const bool is_left = p.left == i;
+      for (int r = x.glo; r < x.glo + x.gcnt; ++r) h->exchanges.push_back({i, x.level, r, is_left ? r + x.gcnt : r - x.gcnt, x.nb, 0});
+      if (p.mine && !x.mine) x.ghost = true;
+    } else if (x.parent >= 0 && N[x.parent].owner != x.owner) {
       h->exchanges.push_back({i, x.level, x.owner, N[x.parent].owner, x.nb, 0});
       if (N[x.parent].mine) x.ghost = true;
     }
@@ -490,6 +510,7 @@ static void mf_parallel(hs_handle* h, int count, F&& body);
 #include "hs_hssfront.h"
 #define MfCoupling NodeH::Coupling
 #include "hs_mffront.h"
+#include "hs_dist.h"
 
 static double front_flops(double ni, double nb) { return (2.0 / 3.0) * ni * ni * ni + 2.0 * ni * ni * nb + 2.0 * ni * nb * nb; }
 
@@ -552,6 +573,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     int64_t swlevel = opts.swlevel < 0 ? std::max<int64_t>(nlev + opts.swlevel, 0) : opts.swlevel;
     for (int i = 0; i < h->nreal; ++i)  // compression_flag of factorization.jl:15 (hs_compress.h); levels of the USER's tree when fronts are split
       N[i].compressed = split.active ? (split.cflag[i] != 0) : hs_compression_flag(N[i].level, N[i].ni, N[i].nb, N[i].leaf, swlevel, opts.swsize);
+    for (int i = 0; i < h->nreal; ++i)
+      if (N[i].dist) N[i].compressed = false;  // fronts eliminated by a group of ranks are eliminated exactly (hs_dist.h)
     if (opts.hss_d > 0 && nranks == 1 && !split.active && swlevel > 0 && !plan_only) {
       // fronts of the compressed levels with a large interior block keep D as an HSS matrix (hs_hssfront.h); the root too
       std::vector<int> where((size_t)n, -1);
@@ -716,6 +739,10 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     hs_create_lookahead_streams(&h->stream_la, &h->stream2m, &h->stream2);
     HS_HIP(hipEventCreate(&h->ev0));
     HS_HIP(hipEventCreate(&h->ev1));
+    if (opts.dist_top && nranks > 1) {
+      HS_HIP(hipStreamCreate(&h->stream_comm));
+      dmalloc((void**)&h->d_gflags, (size_t)nranks * sizeof(int), "group flags");
+    }
     dmalloc(&h->d_fac, fac * sizeof(T), "the factors (LF/UR)");
     dmalloc(&h->d_inv, inv * sizeof(T), "the inverse diagonal blocks");
     HS_HIP(hipMemset(h->d_inv, 0, inv * sizeof(T)));  // identity padding / unwritten corners must read as zero
@@ -795,7 +822,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     if (nranks > 1) {  // the DOFs this rank eliminates, as one index list
       std::vector<int> owned;
       for (int i = 0; i < h->nnodes; ++i)
-        if (N[i].mine) owned.insert(owned.end(), h->fidx_host.begin() + N[i].off_fidx, h->fidx_host.begin() + N[i].off_fidx + N[i].ni);
+        if (N[i].owner == h->rank) owned.insert(owned.end(), h->fidx_host.begin() + N[i].off_fidx, h->fidx_host.begin() + N[i].off_fidx + N[i].ni);
       h->n_owned = (int64_t)owned.size();
       dmalloc((void**)&h->d_owned, owned.size() * sizeof(int), "owned index list");
       if (!owned.empty()) HS_HIP(hipMemcpy(h->d_owned, owned.data(), owned.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -957,7 +984,40 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     // pivoting among its own 32 rows; if any front raised its growth flag the level is assembled again and eliminated with
     // tournament pivoting, and the handle stops trying (a matrix that needs real pivoting needs it everywhere).
     static const bool opt_env = !(getenv("HS_OPTIMISTIC") && getenv("HS_OPTIMISTIC")[0] == '0');
-    const bool try_opt = opt_env && h->optimistic && L.ndense > 0;
+    bool try_opt = opt_env && h->optimistic && L.ndense > 0;
+    const NodeH* dx = (L.mine.size() == 1 && h->nodes[L.mine[0]].dist) ? &h->nodes[L.mine[0]] : nullptr;  // a front eliminated by its group
+    DistFront<T> DF;
+    if (dx) {
+      if (!h->comm) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_options.dist_top needs a communicator (hs_set_comm) before hs_numeric_levels");
+      hipStream_t sc = h->stream_comm;
+      static const int dist_nb = Sched<T>::env_int("HS_DIST_NB", 1024);
+      if (dist_nb < 256 || (dist_nb & (dist_nb - 1))) HS_FAIL(HS_ERR_ARGUMENT, dist_nb, "ArgumentError: HS_DIST_NB = %d must be a power of two >= 256", dist_nb);
+      const size_t nblk32 = (dx->ni + HS_PB - 1) / HS_PB;
+      T* dinv = (T*)h->d_inv;
+      DF = DistFront<T>{h->comm, dx->glo, dx->gcnt, h->rank, dist_nb, sc, dx->ni, dx->nb, dx->m, dx->ldl, dx->ldu, dx->lds,
+                        dfac + dx->off_LF, dfac + dx->off_UR, dsb + dx->off_SB, dinv + dx->off_inv, dinv + dx->off_inv + nblk32 * HS_PB * HS_PB,
+                        dinv + dx->off_inv256, dinv + dx->off_inv256 + (size_t)((dx->ni + 255) / 256) * 65536, h->d_int + dx->off_ipiv};
+      // the join: this rank holds the Schur complement of the child its group eliminated, its partner in the sibling's group the other one
+      const NodeH& cl = h->nodes[dx->left];
+      const NodeH& cr = h->nodes[dx->right];
+      const NodeH& cm = cl.mine ? cl : cr;   // my child
+      const NodeH& co = cl.mine ? cr : cl;   // the sibling's (ghost: its buffer is filled here)
+      const int partner = cl.mine ? h->rank + cm.gcnt : h->rank - cm.gcnt;
+      hipEvent_t ej;
+      HS_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+      HS_HIP(hipEventRecord(ej, s));
+      HS_HIP(hipStreamWaitEvent(sc, ej, 0));
+      std::vector<HsPiece> sends, recvs;
+      if (cm.nb > 0) sends.push_back({partner, cm.ext_sb ? (T*)cm.ext_sb : dsb + cm.off_SB, (size_t)cm.lds * cm.nb * sizeof(T)});
+      if (co.nb > 0) recvs.push_back({partner, co.ext_sb ? (T*)co.ext_sb : dsb + co.off_SB, (size_t)co.lds * co.nb * sizeof(T)});
+      h->comm->transfer(sends, recvs, sc);
+      HS_HIP(hipEventRecord(ej, sc));
+      HS_HIP(hipStreamWaitEvent(s, ej, 0));
+      HS_HIP(hipStreamSynchronize(sc));
+      (void)hipEventDestroy(ej);
+      // every member of the group pivots the same way
+      try_opt = dist_group_or(h->comm, h->d_gflags, dx->glo, dx->gcnt, h->rank, try_opt ? 0 : 1, sc) == 0 && L.ndense > 0;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
     h->prof.tag = lv;
     hipEvent_t ea = h->prof.begin(s);
@@ -983,7 +1043,10 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
       Sched<T> sch{dn, L.ndense, L.dmaxni, L.dmaxnb, L.dmaxm, s, &h->prof, L.h_ni.data(), L.h_nb.data(), h->stream2, 0, h->stream_la, h->stream2m};
       sch.sn = (const SolveNode<T>*)h->d_solve + L.desc_off;  // lu_rec leaves the 256x256 inverse diagonal blocks behind
       sch.optimistic = try_opt && attempt == 0;
-      sch.factor_fronts();
+      if (dx)
+        factor_front_dist<T>(sch, DF);
+      else
+        sch.factor_fronts();
     }
       if (!(try_opt && attempt == 0)) break;
       std::vector<int> gr(h->nnodes);
@@ -992,6 +1055,7 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
       static const bool force_redo = getenv("HS_OPTIMISTIC_FORCE_REDO") != nullptr;  // tests: exercise the redo machinery
       bool redo = force_redo;
       for (int k = 0; k < L.ndense; ++k) redo = redo || gr[L.mine[k]] != 0;
+      if (dx) redo = dist_group_or(h->comm, h->d_gflags, dx->glo, dx->gcnt, h->rank, redo ? 1 : 0, h->stream_comm) != 0;
       if (!redo) break;
       h->optimistic = false;
       if (h->opts.verbose) fprintf(stderr, "[hs] level %d: a pivot outside the diagonal block was needed; redoing the level with tournament pivoting\n", lv);
@@ -1221,6 +1285,11 @@ extern "C" int hs_numeric_begin(hs_handle* h, const void* nzval, int on_device) 
 extern "C" int hs_numeric_levels(hs_handle* h, int64_t lv_from, int64_t lv_to) {
   HS_GUARD(check_handle(h); if (h->is_complex) numeric_levels<cplx>(h, (int)lv_from, (int)lv_to);
            else numeric_levels<double>(h, (int)lv_from, (int)lv_to));
+}
+extern "C" int hs_set_comm(hs_handle* h, hs_comm* c) {
+  HS_GUARD(check_handle(h); if (c && (c->rank != h->rank || c->nranks != h->nranks))
+               HS_FAIL(HS_ERR_ARGUMENT, c->rank, "ArgumentError: communicator is rank %d of %d, the factorization rank %d of %d", c->rank, c->nranks, h->rank, h->nranks);
+           h->comm = c);
 }
 extern "C" int hs_numeric_end(hs_handle* h) { HS_GUARD(check_handle(h); numeric_end(h)); }
 

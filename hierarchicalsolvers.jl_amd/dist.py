@@ -27,7 +27,7 @@ from . import _lib
 from .nesteddissection import flatten_tree
 from .solver import SolverOptions, chkopts
 
-__all__ = ["Plan", "HipBackend", "run_numeric", "run_solve", "StagedSolver", "plan_only", "TorchComm"]
+__all__ = ["Plan", "HipBackend", "run_numeric", "run_solve", "StagedSolver", "plan_only", "TorchComm", "LibComm"]
 
 
 class Plan:
@@ -100,6 +100,118 @@ class TorchComm:
 
     def barrier(self):
         self.dist.barrier()
+
+    def exchange(self, send_t, recv_t, peer):
+        """Pairwise swap with ``peer`` (both sides call it): one batched isend + irecv, so neither side has to go first."""
+        dist, torch = self.dist, self.torch
+        s, r = self._r(send_t), self._r(recv_t)
+        if self.stage and s.is_cuda:
+            hs_, hr = s.cpu(), torch.empty(r.shape, dtype=r.dtype)
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, hs_, peer), dist.P2POp(dist.irecv, hr, peer)]):
+                q.wait()
+            r.copy_(hr)
+        else:
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, s, peer), dist.P2POp(dist.irecv, r, peer)]):
+                q.wait()
+
+
+class LibComm:
+    """The library's own communicator (``hs_comm``, include/hs_solver.h) for ``dist_top`` factorizations: RCCL over xGMI when the
+    process group is ``nccl`` (the 128-byte id travels through torch.distributed once; afterwards the library enqueues grouped
+    ncclSend / ncclRecv on its own stream), host-staged over the process group otherwise (gloo: the single-GPU rehearsals)."""
+
+    def __init__(self, rank, nranks, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.L = _lib.lib()
+        self._h = C.c_void_p()
+        self.rank, self.nranks = int(rank), int(nranks)
+        if dist.get_backend() == "nccl":
+            idt = torch.zeros(128, dtype=torch.uint8, device=device if device is not None else "cuda")
+            if rank == 0:
+                buf = (C.c_char * 128)()
+                _lib.check(self.L.hs_comm_unique_id(C.cast(buf, C.c_void_p)))
+                idt.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            raw = (C.c_char * 128).from_buffer_copy(idt.cpu().numpy().tobytes())
+            _lib.check(self.L.hs_comm_create_rccl(C.cast(raw, C.c_void_p), self.rank, self.nranks, C.byref(self._h)))
+        else:
+            self._cb = _lib.HS_TRANSFER_FN(self._transfer)  # keep the trampoline alive as long as the communicator
+            _lib.check(self.L.hs_comm_create_host(self._cb, None, self.rank, self.nranks, C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def kind(self):
+        return self.L.hs_comm_kind(self._h).decode()
+
+    def selftest(self, nbytes=1 << 20):
+        _lib.check(self.L.hs_comm_selftest(self._h, int(nbytes)))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self.L.hs_comm_free(h)
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def _transfer(user, nsend, speer, sbuf, sbytes, nrecv, rpeer, rbuf, rbytes):
+        """hs_transfer_fn: one host message per peer and direction, moved over the default process group."""
+        try:
+            import torch
+            import torch.distributed as dist
+
+            def view(ptr, nb):
+                return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * int(nb)).from_address(ptr)))
+
+            ops = [dist.P2POp(dist.isend, view(sbuf[k], sbytes[k]), int(speer[k])) for k in range(nsend)]
+            ops += [dist.P2POp(dist.irecv, view(rbuf[k], rbytes[k]), int(rpeer[k])) for k in range(nrecv)]
+            if ops:
+                for q in dist.batch_isend_irecv(ops):
+                    q.wait()
+            return 0
+        except Exception:  # pragma: no cover - reported through the library's error string
+            import traceback
+
+            traceback.print_exc()
+            return 1
+
+
+def run_numeric_dist(backend):
+    """``dist_top``: the library moves everything itself (Schur complements at the joins, block columns inside the groups)."""
+    backend.numeric_begin()
+    backend.numeric_levels(backend.plan.nlevels, 0)
+    backend.numeric_end()
+
+
+def run_solve_dist(backend, plan, rank, comm, b):
+    """``ldiv!`` with the fronts above the cut replicated on their groups: the forward sweep swaps the two children's boundary values
+    between partner ranks before each join, the backward sweep needs nothing (every rank already holds the values of all its
+    ancestors' DOFs), one all-reduce of the disjoint owned pieces at the end."""
+    L, cut = plan.nlevels, plan.cut_level
+    backend.fwd(b, L, cut)
+    for lv in range(cut - 1, 0, -1):
+        mine = [e for e in plan.at_child_level(lv + 1) if e["src"] == rank]
+        theirs = [e for e in plan.at_child_level(lv + 1) if e["dst"] == rank]
+        for em, et in zip(mine, theirs):
+            sbuf = backend.pack_bnd(em["node"], b)
+            rbuf = backend.bnd_buffer(et["node"])
+            backend.sync()
+            comm.exchange(sbuf, rbuf, em["dst"])
+            backend.comm_sync()
+            backend.unpack_bnd(et["node"], b, rbuf)
+        backend.fwd(b, lv, lv)
+    backend.bwd(b, 1, L)
+    out = backend.extract_owned(b)
+    backend.sync()
+    comm.all_reduce(out)
+    backend.comm_sync()
+    backend.assign(b, out)
+    return b
 
 
 def run_numeric(backend, plan, rank, comm):
@@ -190,7 +302,7 @@ def plan_only(A, nd, nd_loc, rank=0, nranks=1, opts=None, **kw):
 class HipBackend:
     """The C ABI behind the schedule.  Device buffers that cross ranks are torch tensors."""
 
-    def __init__(self, A, nd, nd_loc, opts=None, rank=0, nranks=1, device=None, **kw):
+    def __init__(self, A, nd, nd_loc, opts=None, rank=0, nranks=1, device=None, libcomm=None, **kw):
         import torch
 
         self.torch = torch
@@ -227,11 +339,18 @@ class HipBackend:
         self.plan = Plan(self.L.hs_nlevels(h), self.L.hs_cut_level(h), ex, self.nranks)
         # exchange buffers live in torch memory and are registered with the library
         self._schur, self._bnd = {}, {}
+        self.dist_top = bool(opts.dist_top) and self.nranks > 1
+        self.libcomm = None
+        if self.dist_top:  # the library moves the Schur complements and the block columns itself (csrc/hs_dist.h)
+            self._own_libcomm = libcomm is None
+            self.libcomm = libcomm if libcomm is not None else LibComm(self.rank, self.nranks, self.device)
+            _lib.check(self.L.hs_set_comm(h, self.libcomm.handle))
         for e in ex:
             if self.rank in (e["src"], e["dst"]):
-                s = torch.zeros(max(int(e["nelems"]), 1), dtype=self.t_dtype, device=self.device)
-                _lib.check(self.L.hs_set_schur_buffer(h, e["node"], C.c_void_p(s.data_ptr())))
-                self._schur[e["node"]] = s
+                if not self.dist_top:
+                    s = torch.zeros(max(int(e["nelems"]), 1), dtype=self.t_dtype, device=self.device)
+                    _lib.check(self.L.hs_set_schur_buffer(h, e["node"], C.c_void_p(s.data_ptr())))
+                    self._schur[e["node"]] = s
                 self._bnd[e["node"]] = torch.zeros(max(int(e["nb"]), 1), dtype=self.t_dtype, device=self.device)
         self.values = torch.from_numpy(np.ascontiguousarray(A.data, dtype=self.np_dtype)).to(self.device)
 
@@ -239,6 +358,9 @@ class HipBackend:
         h, self._h = getattr(self, "_h", None), None
         if h:
             self.L.hs_free(h)
+        lc, self.libcomm = getattr(self, "libcomm", None), None
+        if lc is not None and getattr(self, "_own_libcomm", False):
+            lc.close()
 
     # -- numeric --------------------------------------------------------------------------------------------
     def set_values(self, values):
@@ -309,8 +431,8 @@ class HipBackend:
 class StagedSolver:
     """analyze once, then ``numeric()`` / ``solve(b)`` with everything resident in HBM."""
 
-    def __init__(self, A, nd, nd_loc, opts=None, rank=0, nranks=1, comm=None, device=None, **kw):
-        self.backend = HipBackend(A, nd, nd_loc, opts, rank, nranks, device, **kw)
+    def __init__(self, A, nd, nd_loc, opts=None, rank=0, nranks=1, comm=None, device=None, libcomm=None, **kw):
+        self.backend = HipBackend(A, nd, nd_loc, opts, rank, nranks, device, libcomm, **kw)
         self.plan = self.backend.plan
         self.rank = rank
         self.comm = comm if comm is not None else (_NullComm() if nranks == 1 else TorchComm())
@@ -318,10 +440,15 @@ class StagedSolver:
     def numeric(self, values=None):
         if values is not None:
             self.backend.set_values(values)
-        run_numeric(self.backend, self.plan, self.rank, self.comm)
+        if self.backend.dist_top:
+            run_numeric_dist(self.backend)
+        else:
+            run_numeric(self.backend, self.plan, self.rank, self.comm)
 
     def solve(self, b):
         """In place on a device tensor ``b`` of length n (every rank passes the same right-hand side)."""
+        if self.backend.dist_top:
+            return run_solve_dist(self.backend, self.plan, self.rank, self.comm, b)
         return run_solve(self.backend, self.plan, self.rank, self.comm, b)
 
     def stats(self):

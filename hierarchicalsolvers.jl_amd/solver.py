@@ -31,7 +31,7 @@ class SolverOptions:
     ``5, 1, 1e-6, 1e-6, 0.5, 32, -1, 10, false`` (HierarchicalSolvers.jl:43-54)."""
 
     _fields = ("swlevel", "swsize", "atol", "rtol", "c_tol", "leafsize", "kest", "stepsize", "verbose")
-    _ext = ("keep_schur", "seed", "profile", "split_size", "hss_min", "hss_dexp", "mf")
+    _ext = ("keep_schur", "seed", "profile", "split_size", "hss_min", "hss_dexp", "mf", "dist_top")
 
     def __init__(self, **kw):
         self.swlevel, self.swsize = 5, 1
@@ -47,6 +47,8 @@ class SolverOptions:
         # matrix-free compressed branch: S leaves flagged fronts as HSS, parents assemble from the children's generators.  True / 'dense': the
         # interior block D of such a parent is expanded and eliminated densely (HSS only where hss_min says so); 2 / 'hss': D is an HSS matrix
         self.mf = False
+        # multi-rank factorizations: fronts above the rank cut are eliminated by all ranks of their group (csrc/hs_dist.h) instead of its first rank
+        self.dist_top = False
         self._set(kw)
 
     def _set(self, kw):
@@ -90,6 +92,7 @@ class SolverOptions:
             o.mf = 3  # interior blocks as the reference's 2x2 block factorization over the children's HSS blocks (blockmatrix.jl:121-130)
         else:
             raise ValueError("mf must be False, True / 'dense', 2 / 'hss' or 3 / 'block'")
+        o.dist_top = 1 if self.dist_top else 0
         if self.hss_dexp is not None:
             if not 0 <= int(self.hss_dexp) <= 12:
                 raise ValueError("hss_dexp must be in 0:12")

@@ -80,7 +80,13 @@ typedef struct hs_options {
                             front), except on the fronts hss_d selects: the dense LU of a 32,768 block takes 0.5 s, its HSS compression +
                             elimination at 1e-4 1.8 s.
                          Single rank only; hs_maxrank includes hssrank(S). */
-  uint8_t reserved[1];
+  uint8_t dist_top;   /* multi-rank factorizations (nranks > 1): 1 = every front ABOVE the rank cut is eliminated by all ranks of its group instead of
+                         the group's first rank (the reference factors the two subtrees of a node one after the other although they are independent,
+                         src/factorization.jl:20-21; above the cut the independent units are the block columns of one front): block columns of
+                         HS_DIST_NB (1024) interior DOFs dealt round-robin over the group, each factored by its owner and fanned out to the group,
+                         every rank updating its own block columns and its slice of the boundary columns; the group ends holding the complete
+                         factors and Schur complement, sibling groups swap Schur complements pairwise at the join.  Needs a communicator
+                         (hs_set_comm).  Fronts above the cut are eliminated exactly in this mode (no compression there). */
   int64_t seed;       /* RNG seed of the randomized compression (reference: Random.seed!(123), test/rungmres.jl:7) */
 } hs_options;
 
@@ -163,6 +169,27 @@ int hs_set_schur_buffer(hs_handle* F, int64_t node, void* dptr);
 int hs_pack_bnd(const hs_handle* F, int64_t node, const void* d_b, void* d_buf, void* stream);   /* buf[j] = b[bnd_j] */
 int hs_unpack_bnd(const hs_handle* F, int64_t node, void* d_b, const void* d_buf, void* stream); /* b[bnd_j] = buf[j] */
 int hs_extract_owned(const hs_handle* F, const void* d_b, void* d_out, void* stream); /* out[int(mine)] = b[int(mine)] */
+
+/* ---- communicator: the one data-movement primitive of a multi-rank factorization (hs_options.dist_top) -------------------------
+ * Every exchange is a set of point-to-point pieces ("send these device ranges to those ranks, receive those from these"), ordered on a
+ * HIP stream.  Two transports:
+ *   hs_comm_create_rccl : RCCL over xGMI (grouped ncclSend / ncclRecv on one world communicator the library creates; librccl is opened
+ *                         with dlopen at this call).  Rank 0 obtains an id with hs_comm_unique_id and the host distributes its 128 bytes
+ *                         with whatever it has (MPI.bcast in a Julia host, torch.distributed here), then every rank calls create.
+ *   hs_comm_create_host : the same operation staged through host memory and moved by a callback of the host layer (MPI.jl; gloo in
+ *                         the single-GPU rehearsals of this repository, where RCCL refuses several ranks on one device).
+ * The callback receives one message per peer and direction (HOST pointers), must complete all of them and return 0. */
+typedef struct hs_comm hs_comm;
+typedef int (*hs_transfer_fn)(void* user, int64_t nsend, const int64_t* send_peer, void* const* send_buf, const int64_t* send_bytes,
+                              int64_t nrecv, const int64_t* recv_peer, void* const* recv_buf, const int64_t* recv_bytes);
+int hs_comm_unique_id(void* id128);
+int hs_comm_create_rccl(const void* id128, int64_t rank, int64_t nranks, hs_comm** out);
+int hs_comm_create_host(hs_transfer_fn fn, void* user, int64_t rank, int64_t nranks, hs_comm** out);
+void hs_comm_free(hs_comm* c);
+const char* hs_comm_kind(const hs_comm* c); /* "rccl" or "host" */
+int hs_comm_selftest(hs_comm* c, int64_t bytes); /* ring shift of a byte pattern (to itself when nranks == 1), checked on the host */
+/* attach a communicator (borrowed: it must outlive the handle's factorizations); rank / nranks must equal the handle's */
+int hs_set_comm(hs_handle* F, hs_comm* c);
 
 /* gmres(A, b; Pr=F, reltol, abstol, restart, maxiter, log=true) -- the call of the reference's scenario (test/rungmres.jl:47-48; IterativeSolvers.jl
  * 0.9.0, not part of the reference tree): restarted GMRES, RIGHT-preconditioned by the factorization `Pr` (NULL: none), every vector resident on

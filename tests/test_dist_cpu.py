@@ -236,3 +236,153 @@ def test_plan_matches_library(hs):
             L.hs_free(h)
     with pytest.raises(ValueError, match="power of two"):
         hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=3)
+
+
+# ---- hs_options.dist_top: fronts above the cut belong to their whole group (csrc/hs_dist.h) -----------------------------------------
+def build_plan_dist(hs, nd, nranks):
+    """Independent restatement of the group rule: a front above the cut is held by every rank of its group; at a join every rank of a
+    child's group swaps with its partner in the sibling's group (rank +- |child group|)."""
+    from hierarchicalsolvers_jl_amd.dist import Plan
+
+    nodes = hs.postorder_nodes(nd)
+    ids = {id(x): k for k, x in enumerate(nodes)}
+    group, level = {}, {}
+
+    def walk(x, lv, lo, cnt):
+        group[ids[id(x)]] = (lo, cnt)
+        level[ids[id(x)]] = lv
+        if x.left is not None:
+            half = cnt // 2 if cnt > 1 else 1
+            walk(x.left, lv + 1, lo, half)
+            walk(x.right, lv + 1, lo + (cnt // 2 if cnt > 1 else 0), half)
+
+    walk(nd, 1, 0, nranks)
+    ex = []
+    for k, x in enumerate(nodes):
+        if x.left is None or group[k][1] == 1:
+            continue
+        for c, sign in ((x.left, +1), (x.right, -1)):
+            ck = ids[id(c)]
+            lo, cnt = group[ck]
+            for r in range(lo, lo + cnt):
+                ex.append(dict(node=ck, level=level[ck], src=r, dst=r + sign * cnt, nb=len(c.bnd), nelems=len(c.bnd) ** 2))
+    p = int(np.log2(nranks))
+    return Plan(max(level.values()), p + 1, ex, nranks), group, level
+
+
+class OracleBackendDist(OracleBackend):
+    """Fronts above the cut are held (and, on the CPU, simply eliminated again) by every member of their group; what is checked is the
+    exchange pattern of the joins and the replicated sweeps of `run_solve_dist`."""
+
+    def __init__(self, A, ond, ond_loc, group, level, rank, plan, comm):
+        owner = {k: (rank if lo <= rank < lo + cnt else lo) for k, (lo, cnt) in group.items()}  # "owner == rank" <=> member of the group
+        super().__init__(A, ond, ond_loc, owner, level, rank)
+        self.first = {k: lo for k, (lo, cnt) in group.items()}
+        self.plan, self.comm = plan, comm
+
+    def numeric_levels(self, lv_from, lv_to):
+        cut = self.plan.cut_level
+        for lv in range(lv_from, max(lv_to, 1) - 1, -1):
+            if lv < cut:  # the join below this level: swap the children's Schur complements with the partner rank
+                mine = [e for e in self.plan.at_child_level(lv + 1) if e["src"] == self.rank]
+                theirs = [e for e in self.plan.at_child_level(lv + 1) if e["dst"] == self.rank]
+                assert len(mine) == 1 and len(theirs) == 1 and mine[0]["dst"] == theirs[0]["src"]
+                nb_s, nb_r = mine[0]["nb"], theirs[0]["nb"]
+                send = self.torch.from_numpy(np.ascontiguousarray(self.F[mine[0]["node"]].S).reshape(-1).astype(self.dtype))
+                recv = self.torch.zeros(nb_r * nb_r, dtype=self.tdtype)
+                assert send.numel() == nb_s * nb_s
+                self.comm.exchange(send, recv, mine[0]["dst"])
+                stub = type("Stub", (), {})()
+                stub.S = recv.numpy().reshape(nb_r, nb_r)
+                self.F[theirs[0]["node"]] = stub
+            super().numeric_levels(lv, lv)
+
+    def extract_owned(self, b):
+        out = np.zeros_like(b)
+        for k in range(len(self.nodes)):
+            if self.first[k] == self.rank and self.owner[k] == self.rank:
+                out[self.nodes[k].int - 1] = b[self.nodes[k].int - 1]
+        return self.torch.from_numpy(out)
+
+
+def _worker_dist(rank, world, port, name, q):
+    try:
+        import torch  # noqa: F401
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hsamd
+
+        hs = hsamd.load()
+        from helpers import prepare
+        from hierarchicalsolvers_jl_amd.dist import TorchComm, run_numeric_dist, run_solve_dist
+        from oracle import hs_oracle as O
+
+        shape, kind, nmax = name
+        P = prepare(hs, shape, kind=kind, nmax=nmax, rhs="randn")
+        plan, group, level = build_plan_dist(hs, P["nd"], world)
+        comm = TorchComm()
+        be = OracleBackendDist(P["A"], P["ond"], P["ond_loc"], group, level, rank, plan, comm)
+        be.plan = plan
+        run_numeric_dist(be)
+        b = np.array(P["b"], dtype=be.dtype)
+        run_solve_dist(be, plan, rank, comm, b)
+        xs = O.ldiv(O.factor(P["A"], P["ond"], P["ond_loc"], swlevel=0), P["b"])  # serial oracle
+        err = float(np.linalg.norm(b - xs) / np.linalg.norm(xs))
+        q.put((rank, err, len(plan.exchanges)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "ERR " + repr(e) + traceback.format_exc(), 0))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("name", [((17, 13), "poisson", 12), ((8, 8, 6), "helmholtz", 30)])
+def test_group_fronts_over_gloo(world, name):
+    """dist_top: replicated fronts above the cut, pairwise swaps at the joins, no communication in the backward sweep."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 7 + world * 29 + len(name[0]) + 101) % 2000
+    procs = [ctx.Process(target=_worker_dist, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, nex in sorted(res):
+        assert not isinstance(err, str), err
+        assert err < 1e-10, (rank, err)
+        assert nex == world * int(np.log2(world))  # every rank swaps once per level above the cut
+
+
+def test_dist_top_plan_matches_library(hs):
+    """hs_plan with dist_top: group membership and the symmetric exchange list equal the independent restatement."""
+    import ctypes as C
+
+    from helpers import prepare
+
+    P = prepare(hs, (20, 12), kind="poisson", nmax=10)
+    L = hs._lib.lib()
+    for world in (2, 4, 8):
+        plan, group, level = build_plan_dist(hs, P["nd"], world)
+        for rank in (0, world - 1):
+            h = hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=rank, nranks=world, dist_top=True)
+            try:
+                assert L.hs_cut_level(h) == plan.cut_level
+                for k, (lo, cnt) in group.items():
+                    assert L.hs_node_owner(h, k) == lo
+                out6 = (C.c_int64 * 6)()
+                got = []
+                for k in range(L.hs_num_exchanges(h)):
+                    hs._lib.check(L.hs_exchange_info(h, k, out6))
+                    got.append((out6[0], out6[1], out6[2], out6[3], out6[4]))
+                want = [(e["node"], e["level"], e["src"], e["dst"], e["nb"]) for e in plan.exchanges]
+                assert sorted(got) == sorted(want)
+            finally:
+                L.hs_free(h)
