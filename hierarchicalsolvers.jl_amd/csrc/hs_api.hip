@@ -239,6 +239,12 @@ struct hs_handle {
   hs_comm* comm = nullptr;           // borrowed (hs_set_comm): moves everything that crosses ranks when hs_options.dist_top is set
   hipStream_t stream_comm = nullptr; // every transfer is enqueued here
   int* d_gflags = nullptr;           // nranks ints: flags agreed inside a group (hs_dist.h)
+  void *d_stage_s = nullptr, *d_stage_r = nullptr;  // packing buffers of the block-column messages (hs_dist.h)
+  // ldiv! of a dist_top factorization inside the library: boundary values swapped at the joins, owned solution pieces gathered at the end
+  void *d_xs = nullptr, *d_xr = nullptr, *d_xall = nullptr;
+  int* d_owned_all = nullptr;            // the DOFs every rank owns, rank after rank
+  std::vector<int64_t> owned_off;        // nranks + 1 offsets into it
+  hipEvent_t ev_ca = nullptr, ev_cb = nullptr;
   Profiler prof;
   void* d_cdesc = nullptr;    // private descriptors (3 per front) of the compressed fronts being eliminated
   size_t cdesc_cap = 0;
@@ -276,6 +282,12 @@ static void free_handle(hs_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->d_gflags) (void)hipFree(h->d_gflags);
+  for (void* q : {h->d_xs, h->d_xr, h->d_xall, (void*)h->d_owned_all})
+    if (q) (void)hipFree(q);
+  if (h->ev_ca) (void)hipEventDestroy(h->ev_ca);
+  if (h->ev_cb) (void)hipEventDestroy(h->ev_cb);
+  if (h->d_stage_s) (void)hipFree(h->d_stage_s);
+  if (h->d_stage_r) (void)hipFree(h->d_stage_r);
   if (h->stream_comm) (void)hipStreamDestroy(h->stream_comm);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream_la) (void)hipStreamDestroy(h->stream_la);
@@ -742,6 +754,31 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     if (opts.dist_top && nranks > 1) {
       HS_HIP(hipStreamCreate(&h->stream_comm));
       dmalloc((void**)&h->d_gflags, (size_t)nranks * sizeof(int), "group flags");
+      size_t stage = 0;
+      const int dist_nb = Sched<T>::env_int("HS_DIST_NB", 1024);
+      for (int i = 0; i < h->nnodes; ++i)
+        if (N[i].dist && N[i].mine) stage = std::max(stage, dist_stage_elems(N[i].ldl, N[i].ni, std::max(dist_nb, 256), sizeof(T)));
+      if (stage > 0) {
+        dmalloc(&h->d_stage_s, stage * sizeof(T), "block-column send buffer");
+        dmalloc(&h->d_stage_r, stage * sizeof(T), "block-column receive buffer");
+      }
+      // ldiv! inside the library: swap buffers for the boundary values of the joins, every rank's owned DOFs
+      int maxnbx = 1;
+      for (auto& ex : h->exchanges) maxnbx = std::max(maxnbx, ex.nb);
+      dmalloc(&h->d_xs, (size_t)maxnbx * sizeof(T), "boundary swap buffer");
+      dmalloc(&h->d_xr, (size_t)maxnbx * sizeof(T), "boundary swap buffer");
+      dmalloc(&h->d_xall, (size_t)n * sizeof(T), "solution gather buffer");
+      std::vector<int> all;
+      h->owned_off.assign(nranks + 1, 0);
+      for (int r = 0; r < nranks; ++r) {
+        for (int i = 0; i < h->nnodes; ++i)
+          if (N[i].owner == r) all.insert(all.end(), h->fidx_host.begin() + N[i].off_fidx, h->fidx_host.begin() + N[i].off_fidx + N[i].ni);
+        h->owned_off[r + 1] = (int64_t)all.size();
+      }
+      dmalloc((void**)&h->d_owned_all, std::max<size_t>(all.size(), 1) * sizeof(int), "owned index lists");
+      if (!all.empty()) HS_HIP(hipMemcpy(h->d_owned_all, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+      HS_HIP(hipEventCreateWithFlags(&h->ev_ca, hipEventDisableTiming));
+      HS_HIP(hipEventCreateWithFlags(&h->ev_cb, hipEventDisableTiming));
     }
     dmalloc(&h->d_fac, fac * sizeof(T), "the factors (LF/UR)");
     dmalloc(&h->d_inv, inv * sizeof(T), "the inverse diagonal blocks");
@@ -996,7 +1033,8 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
       T* dinv = (T*)h->d_inv;
       DF = DistFront<T>{h->comm, dx->glo, dx->gcnt, h->rank, dist_nb, sc, dx->ni, dx->nb, dx->m, dx->ldl, dx->ldu, dx->lds,
                         dfac + dx->off_LF, dfac + dx->off_UR, dsb + dx->off_SB, dinv + dx->off_inv, dinv + dx->off_inv + nblk32 * HS_PB * HS_PB,
-                        dinv + dx->off_inv256, dinv + dx->off_inv256 + (size_t)((dx->ni + 255) / 256) * 65536, h->d_int + dx->off_ipiv};
+                        dinv + dx->off_inv256, dinv + dx->off_inv256 + (size_t)((dx->ni + 255) / 256) * 65536, h->d_int + dx->off_ipiv,
+                        (T*)h->d_stage_s, (T*)h->d_stage_r};
       // the join: this rank holds the Schur complement of the child its group eliminated, its partner in the sibling's group the other one
       const NodeH& cl = h->nodes[dx->left];
       const NodeH& cr = h->nodes[dx->right];
@@ -1210,6 +1248,54 @@ static void solve_bwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
   }
 }
 
+// ldiv! of a dist_top factorization, communication included (every rank passes the same right-hand side and receives the whole
+// solution).  Fronts above the cut are held by every rank of their group, so the forward sweep needs the sibling's boundary values
+// before each join (one pairwise swap), the backward sweep nothing; at the end every rank sends the solution entries it owns to all.
+static void comm_transfer_on(hs_handle* h, const std::vector<HsPiece>& sends, const std::vector<HsPiece>& recvs, hipStream_t s) {
+  HS_HIP(hipEventRecord(h->ev_ca, s));
+  HS_HIP(hipStreamWaitEvent(h->stream_comm, h->ev_ca, 0));
+  h->comm->transfer(sends, recvs, h->stream_comm);
+  HS_HIP(hipEventRecord(h->ev_cb, h->stream_comm));
+  HS_HIP(hipStreamWaitEvent(s, h->ev_cb, 0));
+}
+template <class T>
+static void solve_dist(hs_handle* h, T* db, hipStream_t s) {
+  if (!h->comm) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: ldiv! on a dist_top factorization needs the communicator (hs_set_comm)");
+  const int nl = (int)h->levels.size(), cut = h->cut_level, esz = (int)sizeof(T);
+  solve_fwd<T>(h, db, nl - 1, cut, s);
+  for (int lv = cut - 1; lv >= 1; --lv) {
+    const LevelH& L = h->levels[lv];
+    if (L.mine.size() != 1 || !h->nodes[L.mine[0]].dist) HS_FAIL(HS_ERR_UNSUPPORTED, lv, "internal: level %d above the cut holds no group front", lv);
+    const NodeH& x = h->nodes[L.mine[0]];
+    const NodeH& cl = h->nodes[x.left];
+    const NodeH& cr = h->nodes[x.right];
+    const NodeH& cm = cl.mine ? cl : cr;
+    const NodeH& co = cl.mine ? cr : cl;
+    const int partner = cl.mine ? h->rank + cm.gcnt : h->rank - cm.gcnt;
+    if (cm.nb > 0) launch_pack_idx(h->d_int + cm.off_fidx + cm.ni, cm.nb, db, h->d_xs, esz, s);
+    std::vector<HsPiece> sends, recvs;
+    if (cm.nb > 0) sends.push_back({partner, h->d_xs, (size_t)cm.nb * sizeof(T)});
+    if (co.nb > 0) recvs.push_back({partner, h->d_xr, (size_t)co.nb * sizeof(T)});
+    comm_transfer_on(h, sends, recvs, s);
+    if (co.nb > 0) launch_unpack_idx(h->d_int + co.off_fidx + co.ni, co.nb, db, h->d_xr, esz, s);
+    solve_fwd<T>(h, db, lv, lv, s);
+  }
+  solve_bwd<T>(h, db, 1, nl - 1, s);
+  // gather: all[off[r] ..] = b[owned(r)] on rank r, exchanged all-to-all, scattered back
+  T* all = (T*)h->d_xall;
+  const int64_t* off = h->owned_off.data();
+  const int me = h->rank;
+  if (off[me + 1] > off[me]) launch_pack_idx(h->d_owned_all + off[me], (int)(off[me + 1] - off[me]), db, all + off[me], esz, s);
+  std::vector<HsPiece> sends, recvs;
+  for (int r = 0; r < h->nranks; ++r) {
+    if (r == me) continue;
+    if (off[me + 1] > off[me]) sends.push_back({r, all + off[me], (size_t)(off[me + 1] - off[me]) * sizeof(T)});
+    if (off[r + 1] > off[r]) recvs.push_back({r, all + off[r], (size_t)(off[r + 1] - off[r]) * sizeof(T)});
+  }
+  comm_transfer_on(h, sends, recvs, s);
+  launch_unpack_idx(h->d_owned_all, (int)off[h->nranks], db, all, esz, s);
+}
+
 static void check_solve_args(const hs_handle* h, bool cplx, int64_t ldc, int64_t ldb, int64_t n, int64_t nrhs) {
   check_handle(h);
   if (!h->factored) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: factorization is not complete");
@@ -1221,7 +1307,8 @@ static void check_solve_args(const hs_handle* h, bool cplx, int64_t ldc, int64_t
 template <class T>
 static void ldiv_host(hs_handle* h, T* C, int64_t ldc, const T* B, int64_t ldb, int64_t n, int64_t nrhs) {
   check_solve_args(h, sizeof(T) == 16, ldc, ldb, n, nrhs);
-  if (h->nranks > 1) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_ldiv_* on a distributed factorization: drive hs_solve_*_levels from the host layer");
+  const bool dsolve = h->nranks > 1 && h->opts.dist_top;
+  if (h->nranks > 1 && !dsolve) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_ldiv_* on a distributed factorization without hs_options.dist_top: drive hs_solve_*_levels from the host layer");
   hipStream_t s = h->stream;
   double tsum = 0.0;
   const int nl = (int)h->levels.size();
@@ -1229,8 +1316,12 @@ static void ldiv_host(hs_handle* h, T* C, int64_t ldc, const T* B, int64_t ldb, 
     T* db = (T*)h->d_b;
     HS_HIP(hipMemcpyAsync(db, B + r * ldb, n * sizeof(T), hipMemcpyHostToDevice, s));
     HS_HIP(hipEventRecord(h->ev0, s));
-    solve_fwd<T>(h, db, nl - 1, 0, s);
-    solve_bwd<T>(h, db, 0, nl - 1, s);
+    if (dsolve) {
+      solve_dist<T>(h, db, s);
+    } else {
+      solve_fwd<T>(h, db, nl - 1, 0, s);
+      solve_bwd<T>(h, db, 0, nl - 1, s);
+    }
     HS_HIP(hipEventRecord(h->ev1, s));
     HS_HIP(hipMemcpyAsync(C + r * ldc, db, n * sizeof(T), hipMemcpyDeviceToHost, s));
     HS_HIP(hipStreamSynchronize(s));
@@ -1244,12 +1335,17 @@ static void ldiv_host(hs_handle* h, T* C, int64_t ldc, const T* B, int64_t ldb, 
 template <class T>
 static void ldiv_dev(hs_handle* h, T* dC, int64_t ldc, const T* dB, int64_t ldb, int64_t n, int64_t nrhs, void* stream) {
   check_solve_args(h, sizeof(T) == 16, ldc, ldb, n, nrhs);
-  if (h->nranks > 1) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_ldiv_dev_* on a distributed factorization: drive hs_solve_*_levels from the host layer");
+  const bool dsolve = h->nranks > 1 && h->opts.dist_top;
+  if (h->nranks > 1 && !dsolve) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_ldiv_dev_* on a distributed factorization without hs_options.dist_top: drive hs_solve_*_levels from the host layer");
   hipStream_t s = (hipStream_t)stream;
   const int nl = (int)h->levels.size();
   for (int64_t r = 0; r < nrhs; ++r) {
     T* c = dC + r * ldc;
     if (c != dB + r * ldb) HS_HIP(hipMemcpyAsync(c, dB + r * ldb, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (dsolve) {
+      solve_dist<T>(h, c, s);
+      continue;
+    }
     solve_fwd<T>(h, c, nl - 1, 0, s);
     solve_bwd<T>(h, c, 0, nl - 1, s);
   }

@@ -29,35 +29,75 @@ struct DistFront {
   int ni, nb, m, ldl, ldu, lds;
   T *LF, *UR, *SB, *invL, *invU, *inv256L, *inv256U;
   int* ipiv;            // [ipiv; rperm], 2*ni ints
+  T *stage_s, *stage_r; // packing buffers: every transfer carries at most ONE message per peer and direction
 };
 
-// device pieces of block column j that a rank needs to apply it (and, once all have arrived, to run ldiv! on the front)
-template <class T>
-static void dist_panel_pieces(const DistFront<T>& D, int j, int peer, std::vector<HsPiece>& out) {
-  const int c0 = j * D.NB, w = std::min(D.NB, D.ni - c0);
-  const int nblk32 = (D.ni + HS_PB - 1) / HS_PB, nblk256 = (D.ni + 255) / 256;
-  const int b32 = c0 / HS_PB, n32 = (w + HS_PB - 1) / HS_PB, b256 = c0 / 256, n256 = (w + 255) / 256;
-  (void)nblk32;
-  (void)nblk256;
-  out.push_back({peer, D.LF + (size_t)c0 * D.ldl, (size_t)D.ldl * w * sizeof(T)});
-  out.push_back({peer, D.ipiv, (size_t)2 * D.ni * sizeof(int)});
-  out.push_back({peer, D.invL + (size_t)b32 * HS_PB * HS_PB, (size_t)n32 * HS_PB * HS_PB * sizeof(T)});
-  out.push_back({peer, D.invU + (size_t)b32 * HS_PB * HS_PB, (size_t)n32 * HS_PB * HS_PB * sizeof(T)});
-  out.push_back({peer, D.inv256L + (size_t)b256 * 65536, (size_t)n256 * 65536 * sizeof(T)});
-  out.push_back({peer, D.inv256U + (size_t)b256 * 65536, (size_t)n256 * 65536 * sizeof(T)});
+// Elements of T one block-column message may take: the L part of the widest block column + its inverse diagonal blocks + [ipiv; rperm]
+static inline size_t dist_stage_elems(int m, int ni, int NB, size_t esz) {
+  return (size_t)m * NB + (size_t)2 * (NB / HS_PB) * HS_PB * HS_PB + (size_t)2 * (NB / 256) * 65536 + ((size_t)2 * ni * sizeof(int) + esz - 1) / esz + 64;
 }
 
+// The message of block column j: what a rank needs to APPLY it -- rows c0.. of the column block (the finished L part with Abi*U^-1
+// below it), the 32- and 256-wide inverse diagonal blocks, the pivots and the accumulated row permutation.  `pack` != 0: LF -> stage,
+// else stage -> LF.  Returns the message size in bytes (the same on every rank).
 template <class T>
-static void dist_bcast_panel(const DistFront<T>& D, int j, hipStream_t s) {
+static size_t dist_panel_message(const DistFront<T>& D, int j, T* stage, int pack, hipStream_t s) {
+  const int c0 = j * D.NB, w = std::min(D.NB, D.ni - c0), rows = D.m - c0;
+  const int b32 = c0 / HS_PB, n32 = (w + HS_PB - 1) / HS_PB, b256 = c0 / 256, n256 = (w + 255) / 256;
+  T* q = stage;
+  auto blk = [&](T* dev, size_t cnt) {
+    if (pack == 1) HS_HIP(hipMemcpyAsync(q, dev, cnt * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (pack == 0) HS_HIP(hipMemcpyAsync(dev, q, cnt * sizeof(T), hipMemcpyDeviceToDevice, s));
+    q += cnt;
+  };
+  T* Lp = D.LF + (size_t)c0 * D.ldl + c0;
+  if (pack == 1) HS_HIP(hipMemcpy2DAsync(q, (size_t)rows * sizeof(T), Lp, (size_t)D.ldl * sizeof(T), (size_t)rows * sizeof(T), w, hipMemcpyDeviceToDevice, s));
+  if (pack == 0) HS_HIP(hipMemcpy2DAsync(Lp, (size_t)D.ldl * sizeof(T), q, (size_t)rows * sizeof(T), (size_t)rows * sizeof(T), w, hipMemcpyDeviceToDevice, s));
+  q += (size_t)rows * w;
+  blk(D.invL + (size_t)b32 * HS_PB * HS_PB, (size_t)n32 * HS_PB * HS_PB);
+  blk(D.invU + (size_t)b32 * HS_PB * HS_PB, (size_t)n32 * HS_PB * HS_PB);
+  blk(D.inv256L + (size_t)b256 * 65536, (size_t)n256 * 65536);
+  blk(D.inv256U + (size_t)b256 * 65536, (size_t)n256 * 65536);
+  const size_t ibytes = (size_t)2 * D.ni * sizeof(int);
+  if (pack == 1) HS_HIP(hipMemcpyAsync(q, D.ipiv, ibytes, hipMemcpyDeviceToDevice, s));
+  if (pack == 0) HS_HIP(hipMemcpyAsync(D.ipiv, q, ibytes, hipMemcpyDeviceToDevice, s));
+  return (size_t)((char*)q - (char*)stage) + ibytes;
+}
+
+// fan-out of a packed message from the owner of block j to the rest of the group
+template <class T>
+static void dist_fanout(const DistFront<T>& D, int j, size_t bytes, hipStream_t s) {
   const int owner = D.glo + j % D.gcnt;
   std::vector<HsPiece> sends, recvs;
   if (owner == D.rank) {
     for (int r = D.glo; r < D.glo + D.gcnt; ++r)
-      if (r != D.rank) dist_panel_pieces(D, j, r, sends);
+      if (r != D.rank) sends.push_back({r, D.stage_s, bytes});
   } else {
-    dist_panel_pieces(D, j, owner, recvs);
+    recvs.push_back({owner, D.stage_r, bytes});
   }
   D.comm->transfer(sends, recvs, s);
+}
+
+// The owner has packed block j into stage_s on the stream that factored it; everything else happens on the comm stream.
+template <class T>
+static void dist_bcast_panel(const DistFront<T>& D, int j, hipStream_t s) {
+  const size_t bytes = dist_panel_message(D, j, (T*)nullptr, -1, s);  // size only
+  dist_fanout(D, j, bytes, s);
+  if (D.glo + j % D.gcnt != D.rank) dist_panel_message(D, j, D.stage_r, 0, s);
+}
+
+// The rows ABOVE the diagonal block of block column j (its part of U) are not needed to apply it; they follow off the critical path
+// (every rank ends with the complete factors: the sweeps of ldiv! run replicated above the cut).
+template <class T>
+static void dist_bcast_upper(const DistFront<T>& D, int j, hipStream_t s) {
+  const int c0 = j * D.NB, w = std::min(D.NB, D.ni - c0);
+  if (c0 == 0) return;
+  const bool mine = D.glo + j % D.gcnt == D.rank;
+  const size_t bytes = (size_t)c0 * w * sizeof(T);
+  T* Up = D.LF + (size_t)c0 * D.ldl;
+  if (mine) HS_HIP(hipMemcpy2DAsync(D.stage_s, (size_t)c0 * sizeof(T), Up, (size_t)D.ldl * sizeof(T), (size_t)c0 * sizeof(T), w, hipMemcpyDeviceToDevice, s));
+  dist_fanout(D, j, bytes, s);
+  if (!mine) HS_HIP(hipMemcpy2DAsync(Up, (size_t)D.ldl * sizeof(T), D.stage_r, (size_t)c0 * sizeof(T), (size_t)c0 * sizeof(T), w, hipMemcpyDeviceToDevice, s));
 }
 
 // slice of the boundary columns rank (glo + q) computes
@@ -70,24 +110,22 @@ static inline void dist_bnd_slice(int nb, int gcnt, int q, int& b0, int& b1) {
 template <class T>
 static void dist_allgather_bnd(const DistFront<T>& D, hipStream_t s) {
   if (D.nb == 0) return;
-  std::vector<HsPiece> sends, recvs;
   int mb0, mb1;
   dist_bnd_slice(D.nb, D.gcnt, D.rank - D.glo, mb0, mb1);
-  for (int q = 0; q < D.gcnt; ++q) {
-    const int r = D.glo + q;
-    if (r == D.rank) continue;
-    int b0, b1;
-    dist_bnd_slice(D.nb, D.gcnt, q, b0, b1);
-    if (mb1 > mb0) {
-      sends.push_back({r, D.UR + (size_t)mb0 * D.ldu, (size_t)D.ldu * (mb1 - mb0) * sizeof(T)});
-      sends.push_back({r, D.SB + (size_t)mb0 * D.lds, (size_t)D.lds * (mb1 - mb0) * sizeof(T)});
+  for (int which = 0; which < 2; ++which) {  // column slices are contiguous: no packing; one message per peer and transfer
+    T* base = which == 0 ? D.UR : D.SB;
+    const size_t ld = which == 0 ? D.ldu : D.lds;
+    std::vector<HsPiece> sends, recvs;
+    for (int q = 0; q < D.gcnt; ++q) {
+      const int r = D.glo + q;
+      if (r == D.rank) continue;
+      int b0, b1;
+      dist_bnd_slice(D.nb, D.gcnt, q, b0, b1);
+      if (mb1 > mb0) sends.push_back({r, base + (size_t)mb0 * ld, ld * (mb1 - mb0) * sizeof(T)});
+      if (b1 > b0) recvs.push_back({r, base + (size_t)b0 * ld, ld * (b1 - b0) * sizeof(T)});
     }
-    if (b1 > b0) {
-      recvs.push_back({r, D.UR + (size_t)b0 * D.ldu, (size_t)D.ldu * (b1 - b0) * sizeof(T)});
-      recvs.push_back({r, D.SB + (size_t)b0 * D.lds, (size_t)D.lds * (b1 - b0) * sizeof(T)});
-    }
+    D.comm->transfer(sends, recvs, s);
   }
-  D.comm->transfer(sends, recvs, s);
 }
 
 // The schedule.  `base` is the one-front Sched of the level (stream s = the handle's stream, s2 = the high-priority side stream).
@@ -118,6 +156,7 @@ static void factor_front_dist(Sched<T>& base, const DistFront<T>& D) {
   if (s2 != s) HS_HIP(hipStreamWaitEvent(s2, ev_main, 0));
   if (me == 0) {
     side.lu_rec(0, NB);
+    dist_panel_message(D, 0, D.stage_s, 1, s2);
     HS_HIP(hipEventRecord(ev_fact[0], s2));
     HS_HIP(hipStreamWaitEvent(sc, ev_fact[0], 0));
   }
@@ -136,12 +175,14 @@ static void factor_front_dist(Sched<T>& base, const DistFront<T>& D) {
       HS_HIP(hipEventRecord(ev_main, s));
       HS_HIP(hipStreamWaitEvent(s2, ev_main, 0));
       side.lu_rec(c1, c2);
+      dist_panel_message(D, j + 1, D.stage_s, 1, s2);
       HS_HIP(hipEventRecord(ev_fact[j + 1], s2));
       HS_HIP(hipStreamWaitEvent(sc, ev_fact[j + 1], 0));
     }
     if (has_next) {
       dist_bcast_panel(D, j + 1, sc);
       HS_HIP(hipEventRecord(ev_have[j + 1], sc));
+      dist_bcast_upper(D, j + 1, sc);  // behind the critical message: it travels while the next block column is being factored
     }
     for (int k = j + (next_mine ? 2 : 1); k < nblk; ++k) {  // my other block columns
       if (k % g != me) continue;
@@ -157,8 +198,9 @@ static void factor_front_dist(Sched<T>& base, const DistFront<T>& D) {
     }
     HS_HIP(hipEventRecord(ev_iter[j % 3], s));
   }
-  // every send of this rank has completed (ev_have is recorded behind the transfer on sc) before its block columns change again
-  HS_HIP(hipStreamWaitEvent(s, ev_have[nblk - 1], 0));
+  // every transfer of this front has completed before the block columns change again (left swaps)
+  HS_HIP(hipEventRecord(ev_main, sc));
+  HS_HIP(hipStreamWaitEvent(s, ev_main, 0));
   for (int c0 = 0; c0 + NB < ni; c0 += NB) mn.laswp(HS_MAT_LF, c0, c0 + NB, c0 + NB, HS_BIG);
   if (b1 > b0) mn.gemm(HS_MAT_SB, HS_MAT_UR, 0, HS_BIG, b0, b1, 0, HS_BIG);
   if (D.nb > 0) {

@@ -422,6 +422,12 @@ class HipBackend:
     def assign(self, b, out):
         b.copy_(out)
 
+    def ldiv_dev(self, b):
+        """``ldiv!(F, b)`` inside the library on the caller's current stream (single rank, or ``dist_top`` with the library's communicator)."""
+        f = self.L.hs_ldiv_dev_z if self.is_c else self.L.hs_ldiv_dev_d
+        _lib.check(f(self._h, self._p(b), self.n, self._p(b), self.n, self.n, 1, self._stream()))
+        return b
+
     def stats(self):
         st = _lib.hs_stats()
         _lib.check(self.L.hs_get_stats(self._h, C.byref(st)))
@@ -436,6 +442,9 @@ class StagedSolver:
         self.plan = self.backend.plan
         self.rank = rank
         self.comm = comm if comm is not None else (_NullComm() if nranks == 1 else TorchComm())
+        # dist_top: ldiv! runs inside the library too (hs_ldiv_dev_*: swaps at the joins and the final gather through the library's
+        # communicator); host_solve = True drives the same sweeps level by level from here (run_solve_dist, torch.distributed)
+        self.host_solve = False
 
     def numeric(self, values=None):
         if values is not None:
@@ -448,6 +457,8 @@ class StagedSolver:
     def solve(self, b):
         """In place on a device tensor ``b`` of length n (every rank passes the same right-hand side)."""
         if self.backend.dist_top:
+            if not self.host_solve:
+                return self.backend.ldiv_dev(b)
             return run_solve_dist(self.backend, self.plan, self.rank, self.comm, b)
         return run_solve(self.backend, self.plan, self.rank, self.comm, b)
 

@@ -37,6 +37,7 @@ def _worker(rank, world, port, name, q, fopts=None, env=None):
         # SuperLU takes minutes on the larger / complex 3-D cases: there the bar is the residual (the exact path sits at round-off level)
         xr = spla.splu(P["A"]).solve(P["b"]) if (P["A"].shape[0] <= 40000 and not np.iscomplexobj(P["A"].data)) or P["A"].shape[0] <= 5000 else None
         for rep in range(2):  # numeric twice: the second pass re-uses every buffer
+            S.host_solve = rep == 1  # dist_top: ldiv! inside the library first, then the host-driven sweeps (dist.run_solve_dist)
             S.numeric()
             b = torch.from_numpy(np.ascontiguousarray(P["b"])).to(dev)
             S.solve(b)
