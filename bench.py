@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--mf", nargs="?", const=1, default=0, type=int, help="matrix-free compressed branch: S travels between the compressed fronts as HSS matrices (the reference's data flow); 1 = interior blocks of those fronts dense (unless --hss-min), 2 = one HSS matrix, 3 = the reference's 2x2 block factorization over HSS blocks")
     ap.add_argument("--dist-top", type=int, default=-1, help="N > 1: fronts above the rank cut eliminated by their whole group of ranks (csrc/hs_dist.h, RCCL inside the library); "
                     "-1 = on for exact runs when the library's communicator passes its self-test on every rank, 0 = off (subtree-per-rank only: the group's first rank eliminates them)")
+    ap.add_argument("--dist-min-gbps", type=float, default=12.0, help="--dist-top -1: minimum measured point-to-point rate (ring shift of 128 MiB through the library's communicator, slowest rank)")
     ap.add_argument("--leafsize", type=int, default=32, help="SolverOptions.leafsize (HSS leaves; the device uses at least 128)")
     args = ap.parse_args()
 
@@ -242,22 +243,27 @@ def main():
     is_c = np.iscomplexobj(Ap.data)
 
     fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol, split_size=args.split, hss_min=args.hss_min, hss_dexp=args.hss_dexp, mf=args.mf, leafsize=args.leafsize) if args.swlevel != 0 else dict(swlevel=0)
-    libcomm, dist_note = None, None
+    libcomm, dist_note, p2p_gbps = None, None, 0.0
     if world > 1 and args.dist_top != 0 and args.swlevel == 0:
         # the library's own communicator (RCCL over xGMI under the nccl process group): used only if its ring self-test passes on EVERY rank
-        ok = 1
+        # AND moves at least --dist-min-gbps per link (a fan-out slower than that would cost more than the idle ranks gain)
+        ok, bw = 1, 0.0
         try:
             libcomm = hsdist.LibComm(rank, world, dev)
             libcomm.selftest(1 << 22)
+            bw = libcomm.bandwidth(1 << 27, 4)
         except Exception as e:  # noqa: BLE001
             ok, dist_note = 0, f"rank {rank}: {e!r}"
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        on_dev = torch.distributed.get_backend() == "nccl"
+        flag = torch.tensor([float(ok), bw], dtype=torch.float64, device=dev if on_dev else "cpu")
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+        p2p_gbps = float(flag[1].item())
+        if int(flag[0].item()) == 1 and (p2p_gbps >= args.dist_min_gbps or libcomm.kind() == "host" or args.dist_top == 1):
             fopts["dist_top"] = True
         else:
+            dist_note = dist_note or ("the communicator self-test failed on another rank" if int(flag[0].item()) != 1 else
+                                      f"point-to-point rate {p2p_gbps:.1f} GB/s below --dist-min-gbps {args.dist_min_gbps:g}")
             libcomm = None
-            dist_note = dist_note or "the communicator self-test failed on another rank"
     t0 = time.perf_counter()
     S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, libcomm=libcomm, **fopts)
     torch.cuda.synchronize(dev)
@@ -410,6 +416,8 @@ def main():
         }
         if dist_note:
             out["dist_top_note"] = dist_note
+        if world > 1 and args.dist_top != 0 and args.swlevel == 0:
+            out["comm_p2p_GBps"] = p2p_gbps  # measured through the library's communicator before the run (slowest rank)
         if flops:
             out["factor_tflops_minimal_count"] = flops / st["t_total"] / 1e12
         if world == 1 and t_ldiv > 0 and st["bytes_solve"] > 0:

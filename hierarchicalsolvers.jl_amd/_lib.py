@@ -76,7 +76,7 @@ EXPORTS = [
     "hs_analyze", "hs_plan", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned", "hs_gmres_d", "hs_gmres_z",
-    "hs_comm_unique_id", "hs_comm_create_rccl", "hs_comm_create_host", "hs_comm_free", "hs_comm_kind", "hs_comm_selftest", "hs_set_comm",
+    "hs_comm_unique_id", "hs_comm_create_rccl", "hs_comm_create_host", "hs_comm_free", "hs_comm_kind", "hs_comm_selftest", "hs_comm_bandwidth", "hs_set_comm",
     "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_compress_lru_multi_d", "hs_hss_compress_lru_multi_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_expand", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_trim", "hs_hss_free", "hs_node_schur_hss",
@@ -167,6 +167,8 @@ def lib():
     L.hs_comm_kind.restype = C.c_char_p
     L.hs_comm_selftest.argtypes = [vp, i64]
     L.hs_comm_selftest.restype = C.c_int
+    L.hs_comm_bandwidth.argtypes = [vp, i64, i64, C.POINTER(C.c_double)]
+    L.hs_comm_bandwidth.restype = C.c_int
     L.hs_set_comm.argtypes = [vp, vp]
     L.hs_set_comm.restype = C.c_int
     for f in (L.hs_gmres_d, L.hs_gmres_z):

@@ -239,6 +239,7 @@ struct hs_handle {
   hs_comm* comm = nullptr;           // borrowed (hs_set_comm): moves everything that crosses ranks when hs_options.dist_top is set
   hipStream_t stream_comm = nullptr; // every transfer is enqueued here
   int* d_gflags = nullptr;           // nranks ints: flags agreed inside a group (hs_dist.h)
+  void* d_stage_u = nullptr;
   void *d_stage_s = nullptr, *d_stage_r = nullptr;  // packing buffers of the block-column messages (hs_dist.h)
   // ldiv! of a dist_top factorization inside the library: boundary values swapped at the joins, owned solution pieces gathered at the end
   void *d_xs = nullptr, *d_xr = nullptr, *d_xall = nullptr;
@@ -286,6 +287,7 @@ static void free_handle(hs_handle* h) {
     if (q) (void)hipFree(q);
   if (h->ev_ca) (void)hipEventDestroy(h->ev_ca);
   if (h->ev_cb) (void)hipEventDestroy(h->ev_cb);
+  if (h->d_stage_u) (void)hipFree(h->d_stage_u);
   if (h->d_stage_s) (void)hipFree(h->d_stage_s);
   if (h->d_stage_r) (void)hipFree(h->d_stage_r);
   if (h->stream_comm) (void)hipStreamDestroy(h->stream_comm);
@@ -761,6 +763,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
       if (stage > 0) {
         dmalloc(&h->d_stage_s, stage * sizeof(T), "block-column send buffer");
         dmalloc(&h->d_stage_r, stage * sizeof(T), "block-column receive buffer");
+        dmalloc(&h->d_stage_u, stage * sizeof(T), "block-column send buffer (U parts)");
       }
       // ldiv! inside the library: swap buffers for the boundary values of the joins, every rank's owned DOFs
       int maxnbx = 1;
@@ -1031,10 +1034,11 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
       if (dist_nb < 256 || (dist_nb & (dist_nb - 1))) HS_FAIL(HS_ERR_ARGUMENT, dist_nb, "ArgumentError: HS_DIST_NB = %d must be a power of two >= 256", dist_nb);
       const size_t nblk32 = (dx->ni + HS_PB - 1) / HS_PB;
       T* dinv = (T*)h->d_inv;
-      DF = DistFront<T>{h->comm, dx->glo, dx->gcnt, h->rank, dist_nb, sc, dx->ni, dx->nb, dx->m, dx->ldl, dx->ldu, dx->lds,
+      static const int dist_period = std::max(1, Sched<T>::env_int("HS_DIST_PERIOD", 1));
+      DF = DistFront<T>{h->comm, dx->glo, dx->gcnt, h->rank, dist_nb, dist_period, sc, dx->ni, dx->nb, dx->m, dx->ldl, dx->ldu, dx->lds,
                         dfac + dx->off_LF, dfac + dx->off_UR, dsb + dx->off_SB, dinv + dx->off_inv, dinv + dx->off_inv + nblk32 * HS_PB * HS_PB,
                         dinv + dx->off_inv256, dinv + dx->off_inv256 + (size_t)((dx->ni + 255) / 256) * 65536, h->d_int + dx->off_ipiv,
-                        (T*)h->d_stage_s, (T*)h->d_stage_r};
+                        (T*)h->d_stage_s, (T*)h->d_stage_r, (T*)h->d_stage_u};
       // the join: this rank holds the Schur complement of the child its group eliminated, its partner in the sibling's group the other one
       const NodeH& cl = h->nodes[dx->left];
       const NodeH& cr = h->nodes[dx->right];

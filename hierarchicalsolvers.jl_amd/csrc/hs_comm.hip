@@ -242,3 +242,19 @@ extern "C" int hs_comm_selftest(hs_comm* c, int64_t bytes) {
       HS_HIP(hipMemcpyAsync(b.data(), r, bytes, hipMemcpyDeviceToHost, s)); HS_HIP(hipStreamSynchronize(s)); (void)hipFree(d); (void)hipFree(r);
       (void)hipStreamDestroy(s); if (memcmp(a.data(), b.data(), bytes) != 0) HS_COMM_FAIL(HS_ERR_DEVICE, "communicator self-test: received bytes differ from the sender's"));
 }
+
+// Point-to-point rate of the transport: `reps` ring shifts of `bytes` bytes (rank r -> r+1), device to device, timed with HIP events on
+// the stream the transfers are enqueued on.  *gbps = bytes sent per rank / time (GB/s; one xGMI link per direction under RCCL).
+extern "C" int hs_comm_bandwidth(hs_comm* c, int64_t bytes, int64_t reps, double* gbps) {
+  HS_COMM_GUARD(
+      if (!c || bytes <= 0 || reps <= 0 || !gbps) HS_COMM_FAIL(HS_ERR_ARGUMENT, "ArgumentError: communicator / sizes"); *gbps = 0.0;
+      if (c->nranks < 2) return HS_OK; unsigned char* d = nullptr; unsigned char* r = nullptr; HS_HIP(hipMalloc((void**)&d, bytes));
+      HS_HIP(hipMalloc((void**)&r, bytes)); hipStream_t s; HS_HIP(hipStreamCreate(&s)); hipEvent_t e0, e1; HS_HIP(hipEventCreate(&e0)); HS_HIP(hipEventCreate(&e1));
+      HS_HIP(hipMemsetAsync(d, 1, bytes, s)); const int next = (c->rank + 1) % c->nranks, prev = (c->rank - 1 + c->nranks) % c->nranks;
+      c->transfer({HsPiece{next, d, (size_t)bytes}}, {HsPiece{prev, r, (size_t)bytes}}, s);  // warm-up: connections are set up on first use
+      HS_HIP(hipStreamSynchronize(s)); HS_HIP(hipEventRecord(e0, s));
+      for (int64_t k = 0; k < reps; ++k) c->transfer({HsPiece{next, d, (size_t)bytes}}, {HsPiece{prev, r, (size_t)bytes}}, s);
+      HS_HIP(hipEventRecord(e1, s)); HS_HIP(hipStreamSynchronize(s)); float ms = 0.f; HS_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (ms > 0.f) *gbps = (double)bytes * (double)reps / (ms * 1e-3) / 1e9; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d); (void)hipFree(r);
+      (void)hipStreamDestroy(s));
+}

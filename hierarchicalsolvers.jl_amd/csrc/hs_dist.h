@@ -24,12 +24,15 @@ struct DistFront {
   hs_comm* comm;
   int glo, gcnt, rank;  // group [glo, glo+gcnt), this rank's world rank
   int NB;
+  int period;           // consecutive block columns one rank owns (HS_DIST_PERIOD, default 1): owner(j) = glo + (j / period) % gcnt
   hipStream_t sc;       // every transfer of the handle is enqueued here (one order of operations on the communicator)
   // the front
   int ni, nb, m, ldl, ldu, lds;
   T *LF, *UR, *SB, *invL, *invU, *inv256L, *inv256U;
   int* ipiv;            // [ipiv; rperm], 2*ni ints
   T *stage_s, *stage_r; // packing buffers: every transfer carries at most ONE message per peer and direction
+  T* stage_u;           // sender's buffer of the U parts (they travel behind the block-column messages and must not hold up the next pack)
+  int owner(int j) const { return glo + (j / period) % gcnt; }
 };
 
 // Elements of T one block-column message may take: the L part of the widest block column + its inverse diagonal blocks + [ipiv; rperm]
@@ -66,12 +69,12 @@ static size_t dist_panel_message(const DistFront<T>& D, int j, T* stage, int pac
 
 // fan-out of a packed message from the owner of block j to the rest of the group
 template <class T>
-static void dist_fanout(const DistFront<T>& D, int j, size_t bytes, hipStream_t s) {
-  const int owner = D.glo + j % D.gcnt;
+static void dist_fanout(const DistFront<T>& D, int j, T* from, size_t bytes, hipStream_t s) {
+  const int owner = D.owner(j);
   std::vector<HsPiece> sends, recvs;
   if (owner == D.rank) {
     for (int r = D.glo; r < D.glo + D.gcnt; ++r)
-      if (r != D.rank) sends.push_back({r, D.stage_s, bytes});
+      if (r != D.rank) sends.push_back({r, from, bytes});
   } else {
     recvs.push_back({owner, D.stage_r, bytes});
   }
@@ -82,8 +85,8 @@ static void dist_fanout(const DistFront<T>& D, int j, size_t bytes, hipStream_t 
 template <class T>
 static void dist_bcast_panel(const DistFront<T>& D, int j, hipStream_t s) {
   const size_t bytes = dist_panel_message(D, j, (T*)nullptr, -1, s);  // size only
-  dist_fanout(D, j, bytes, s);
-  if (D.glo + j % D.gcnt != D.rank) dist_panel_message(D, j, D.stage_r, 0, s);
+  dist_fanout(D, j, D.stage_s, bytes, s);
+  if (D.owner(j) != D.rank) dist_panel_message(D, j, D.stage_r, 0, s);
 }
 
 // The rows ABOVE the diagonal block of block column j (its part of U) are not needed to apply it; they follow off the critical path
@@ -92,11 +95,11 @@ template <class T>
 static void dist_bcast_upper(const DistFront<T>& D, int j, hipStream_t s) {
   const int c0 = j * D.NB, w = std::min(D.NB, D.ni - c0);
   if (c0 == 0) return;
-  const bool mine = D.glo + j % D.gcnt == D.rank;
+  const bool mine = D.owner(j) == D.rank;
   const size_t bytes = (size_t)c0 * w * sizeof(T);
   T* Up = D.LF + (size_t)c0 * D.ldl;
-  if (mine) HS_HIP(hipMemcpy2DAsync(D.stage_s, (size_t)c0 * sizeof(T), Up, (size_t)D.ldl * sizeof(T), (size_t)c0 * sizeof(T), w, hipMemcpyDeviceToDevice, s));
-  dist_fanout(D, j, bytes, s);
+  if (mine) HS_HIP(hipMemcpy2DAsync(D.stage_u, (size_t)c0 * sizeof(T), Up, (size_t)D.ldl * sizeof(T), (size_t)c0 * sizeof(T), w, hipMemcpyDeviceToDevice, s));
+  dist_fanout(D, j, D.stage_u, bytes, s);
   if (!mine) HS_HIP(hipMemcpy2DAsync(Up, (size_t)D.ldl * sizeof(T), D.stage_r, (size_t)c0 * sizeof(T), (size_t)c0 * sizeof(T), w, hipMemcpyDeviceToDevice, s));
 }
 
@@ -134,6 +137,8 @@ static void factor_front_dist(Sched<T>& base, const DistFront<T>& D) {
   const int NB = D.NB, ni = D.ni, g = D.gcnt, me = D.rank - D.glo;
   const int nblk = (ni + NB - 1) / NB;
   if (nblk <= 0) return;
+  auto mine = [&](int j) { return D.owner(j) == D.rank; };
+  int last_packed = -1;  // my latest block column whose message sits in stage_s: its send must be over before the next pack
   Sched<T> mn = base, side = base;
   mn.s2 = nullptr;
   mn.s_la = nullptr;
@@ -154,9 +159,10 @@ static void factor_front_dist(Sched<T>& base, const DistFront<T>& D) {
   HS_HIP(hipEventRecord(ev_main, s));
   HS_HIP(hipStreamWaitEvent(sc, ev_main, 0));
   if (s2 != s) HS_HIP(hipStreamWaitEvent(s2, ev_main, 0));
-  if (me == 0) {
+  if (mine(0)) {
     side.lu_rec(0, NB);
     dist_panel_message(D, 0, D.stage_s, 1, s2);
+    last_packed = 0;
     HS_HIP(hipEventRecord(ev_fact[0], s2));
     HS_HIP(hipStreamWaitEvent(sc, ev_fact[0], 0));
   }
@@ -166,8 +172,8 @@ static void factor_front_dist(Sched<T>& base, const DistFront<T>& D) {
     const int c0 = j * NB, c1 = c0 + NB, c2 = c1 + NB;
     const bool has_next = j + 1 < nblk;
     if (j >= 3) HS_HIP(hipEventSynchronize(ev_iter[j % 3]));  // bounded host run-ahead (see factor_fronts_lookahead)
-    HS_HIP(hipStreamWaitEvent(s, (j % g == me) ? ev_fact[j] : ev_have[j], 0));
-    const bool next_mine = has_next && ((j + 1) % g == me);
+    HS_HIP(hipStreamWaitEvent(s, mine(j) ? ev_fact[j] : ev_have[j], 0));
+    const bool next_mine = has_next && mine(j + 1);
     if (next_mine) {  // look-ahead: my next block column first, factored on the side stream while the rest is updated
       mn.laswp(HS_MAT_LF, c1, c2, c0, c1);
       mn.trsm_rec(HS_MAT_LF, c0, c1, c1, c2);
@@ -175,7 +181,9 @@ static void factor_front_dist(Sched<T>& base, const DistFront<T>& D) {
       HS_HIP(hipEventRecord(ev_main, s));
       HS_HIP(hipStreamWaitEvent(s2, ev_main, 0));
       side.lu_rec(c1, c2);
+      if (last_packed >= 0) HS_HIP(hipStreamWaitEvent(s2, ev_have[last_packed], 0));  // recorded behind that block's fan-out on the comm stream
       dist_panel_message(D, j + 1, D.stage_s, 1, s2);
+      last_packed = j + 1;
       HS_HIP(hipEventRecord(ev_fact[j + 1], s2));
       HS_HIP(hipStreamWaitEvent(sc, ev_fact[j + 1], 0));
     }
@@ -185,7 +193,7 @@ static void factor_front_dist(Sched<T>& base, const DistFront<T>& D) {
       dist_bcast_upper(D, j + 1, sc);  // behind the critical message: it travels while the next block column is being factored
     }
     for (int k = j + (next_mine ? 2 : 1); k < nblk; ++k) {  // my other block columns
-      if (k % g != me) continue;
+      if (!mine(k)) continue;
       const int k0 = k * NB, k1 = k0 + NB;
       mn.laswp(HS_MAT_LF, k0, k1, c0, c1);
       mn.trsm_rec(HS_MAT_LF, c0, c1, k0, k1);

@@ -137,15 +137,18 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
   // clamped 8-byte loads + selects: a per-lane `if (in range) load` compiles to a branch with an
   // s_waitcnt vmcnt(0) at every join, i.e. eight fully serialised memory round trips per K-step
   // (that cost 33 % of every wave's life in SQ_WAIT_ANY before this was restructured).
-  const bool interior = (m0 + BM <= M) && (n0 + BN <= N);
+  // Ragged batches (fronts of one level differ in ni / nb) give EVERY front an edge tile in n: at the leaf level of Poisson 128^3 9-17 %
+  // of all tiles, which the clamped 8-byte path made 4-5x slower than interior ones (the level ran at the rate of its bounding box).
+  // The operands are independent: a tile whose rows are all inside takes the 16-byte A loads whatever its columns do, and for a full
+  // K-step the B loads stay 16 bytes wide with the COLUMN clamped -- what lands in columns >= N only feeds accumulators that are
+  // never stored (C[:, n] depends on B[:, n] alone).  Only a partial K-step (the last one of a tile) needs the zero-filling path.
+  const bool rows_in = (m0 + BM <= M), rows_even = (M & 1) == 0;  // M >= 2 when even (M > 0)
   auto load_tile = [&](int k0) {
-    if (interior && k0 + BK <= K) {
+    const bool kfull = k0 + BK <= K;
+    if ((rows_in || rows_even) && kfull) {  // an even row count: a row pair is inside or outside as a whole, outside pairs re-read the last one
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        ra[i] = gld2(A + (size_t)(m0 + 2 * a_pair) + (size_t)(k0 + a_k + 4 * i) * p.lda);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        rb[i] = gld2(B + (size_t)(k0 + 2 * b_kp) + (size_t)(n0 + b_n + 32 * i) * p.ldb);
+        ra[i] = gld2(A + (size_t)min(m0 + 2 * a_pair, M - 2) + (size_t)(k0 + a_k + 4 * i) * p.lda);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -156,6 +159,12 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
         ra[i].x = (kok && mm < M) ? x : 0.0;
         ra[i].y = (kok && mm + 1 < M) ? y : 0.0;
       }
+    }
+    if (kfull) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rb[i] = gld2(B + (size_t)(k0 + 2 * b_kp) + (size_t)min(n0 + b_n + 32 * i, N - 1) * p.ldb);
+    } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int nn = n0 + b_n + 32 * i, kk = k0 + 2 * b_kp;

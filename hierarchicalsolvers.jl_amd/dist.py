@@ -150,6 +150,12 @@ class LibComm:
     def selftest(self, nbytes=1 << 20):
         _lib.check(self.L.hs_comm_selftest(self._h, int(nbytes)))
 
+    def bandwidth(self, nbytes=1 << 26, reps=4):
+        """GB/s each rank sends in a ring shift (device to device through this transport; every rank calls it)."""
+        g = C.c_double(0.0)
+        _lib.check(self.L.hs_comm_bandwidth(self._h, int(nbytes), int(reps), C.byref(g)))
+        return g.value
+
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

@@ -188,6 +188,7 @@ int hs_comm_create_host(hs_transfer_fn fn, void* user, int64_t rank, int64_t nra
 void hs_comm_free(hs_comm* c);
 const char* hs_comm_kind(const hs_comm* c); /* "rccl" or "host" */
 int hs_comm_selftest(hs_comm* c, int64_t bytes); /* ring shift of a byte pattern (to itself when nranks == 1), checked on the host */
+int hs_comm_bandwidth(hs_comm* c, int64_t bytes, int64_t reps, double* gbps); /* ring shifts timed on the transfer stream: GB/s sent per rank (0 when nranks == 1) */
 /* attach a communicator (borrowed: it must outlive the handle's factorizations); rank / nranks must equal the handle's */
 int hs_set_comm(hs_handle* F, hs_comm* c);
 

@@ -50,6 +50,7 @@ def _worker(rank, world, port, name, q, fopts=None, env=None):
         nmine = sum(1 for k in range(len(hs.postorder_nodes(P["nd"]))) if S.backend.L.hs_node_owner(S.backend._h, k) == rank)
         if S.backend.libcomm is not None:
             S.backend.libcomm.selftest(1 << 16)  # ring shift through the communicator the factorization used
+            assert S.backend.libcomm.bandwidth(1 << 20, 2) > 0.0
         q.put((rank, max(errs), nmine))
         dist.barrier()
         dist.destroy_process_group()
@@ -118,15 +119,17 @@ def test_two_ranks_compressed_fronts():
         assert err < 1e3 * tol, (rank, err)
 
 
-@pytest.mark.parametrize("world,name,nb", [(2, "poisson3d_32", 256), (4, "poisson3d_32", 256), (2, "helmholtz3d_32", 256), (4, "helmholtz2d_p1_h64_nmax100", 256),
-                                           (2, "poisson3d_32", 1024), (2, "poisson3d_64", 1024)])
-def test_group_fronts_one_gpu(world, name, nb):
+@pytest.mark.parametrize("world,name,nb,period", [(2, "poisson3d_32", 256, 1), (4, "poisson3d_32", 256, 1), (2, "helmholtz3d_32", 256, 1),
+                                                  (4, "helmholtz2d_p1_h64_nmax100", 256, 1), (2, "poisson3d_32", 1024, 1), (2, "poisson3d_64", 1024, 1),
+                                                  (2, "poisson3d_32", 256, 2), (2, "poisson3d_64", 256, 4)])
+def test_group_fronts_one_gpu(world, name, nb, period):
     """hs_options.dist_top: the fronts above the rank cut are eliminated by all ranks of their group (csrc/hs_dist.h) -- block columns of
     HS_DIST_NB interior DOFs dealt round-robin, factored by their owner, fanned out, boundary-column slices gathered at the end -- through
     the host-staged communicator (gloo moves the bytes; RCCL refuses several ranks on one device).  Same bar as the rank-local path:
-    the solution agrees with SuperLU to 1e-10 after two numeric passes."""
-    port = 29500 + (os.getpid() * 11 + world * 19 + len(name) + nb) % 2000
-    res = _run_ranks(world, lambda r, q: (r, world, port, name, q, dict(swlevel=0, dist_top=True), {"HS_DIST_NB": str(nb)}))
+    the solution agrees with SuperLU to 1e-10 after two numeric passes.  `period` > 1: several consecutive block columns per owner (the
+    fan-out of one overlaps the factorization of the next)."""
+    port = 29500 + (os.getpid() * 11 + world * 19 + len(name) + nb + period) % 2000
+    res = _run_ranks(world, lambda r, q: (r, world, port, name, q, dict(swlevel=0, dist_top=True), {"HS_DIST_NB": str(nb), "HS_DIST_PERIOD": str(period)}))
     for rank, err, nmine in res:
         assert not isinstance(err, str), err
         assert err < 1e-10, (rank, err)

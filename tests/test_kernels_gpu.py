@@ -42,7 +42,7 @@ def run_gemm(hs, M, N, K, cplx, minus, pad=(0, 0, 0), seed=0):
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize(
     "M,N,K",
-    [(128, 128, 16), (128, 128, 64), (256, 128, 32), (64, 64, 64), (1, 1, 1), (17, 5, 3), (129, 127, 33), (300, 257, 100), (513, 64, 250), (31, 400, 16), (1000, 999, 7)],
+    [(128, 128, 16), (128, 128, 64), (256, 128, 32), (64, 64, 64), (1, 1, 1), (17, 5, 3), (129, 127, 33), (300, 257, 100), (513, 64, 250), (31, 400, 16), (1000, 999, 7), (258, 300, 64), (2, 130, 32), (384, 200, 48), (130, 1, 16)],
 )
 def test_gemm_shapes(hs, M, N, K, cplx):
     run_gemm(hs, M, N, K, cplx, minus=True, pad=(2, 3, 1), seed=M + N + K)
