@@ -19,6 +19,7 @@
 //   laswp applies the swaps to the other columns as the recursion demands (inv(L11) goes through the MFMA tile code: trsm_inv_kernel).
 //
 // All kernels are "grouped": blockIdx.y selects the front of the current level batch.
+#include <cstdlib>
 #include "hs_common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -479,6 +480,209 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// panel_pivot, OPTIMISTIC pivoting, Float64 -- the chain link of a panel step, cut to one elimination.
+// The general kernel above searches the pivots with one register elimination, turns the winners into swaps, applies them in
+// global memory, re-reads the swapped block and eliminates it AGAIN for L, U and both inverses: four dependent 32-step loops
+// and seven dependent memory round trips in ONE wave (59 us alone on the device, 140 us next to a running GEMM -- 40 % of
+// the panel chain a lone front waits for, tools/factor_trace.sh).  With optimistic pivoting every pivot comes from the block's
+// own 32 rows, so nothing outside the 32 x 32 block moves:
+//   wave 0   ONE elimination with the pivot search inside it (lane = row, implicit permutation: a row that wins step k keeps its
+//            lane and takes position k); it leaves L\U in LDS in pivoted order;
+//   then, concurrently,  wave 1: inv(L)   wave 2: inv(U)   wave 3: U12 = L^-1 * (P*A12) by forward substitution (fuse & 1)
+//            wave 0: swaps for `laswp` (ipiv), the pivoted rows of the previous 32 columns (fuse & 2), rperm, the L\U block;
+//   the side blocks were loaded into LDS by waves 1-3 WHILE wave 0 eliminated.  One barrier, two memory round trips on the chain.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void panel_pivot_opt_kernel(const NodeDesc<double>* __restrict__ nodes, int pb, int fuse) {
+  __builtin_amdgcn_s_setprio(3);
+  const NodeDesc<double> nd = nodes[blockIdx.y];
+  const int c0 = pb * HS_PB;
+  if (c0 >= nd.ni) return;
+  const int w = min(HS_PB, nd.ni - c0);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int w2 = (fuse & 1) ? max(0, min(HS_PB, nd.ni - (c0 + HS_PB))) : 0;
+  const bool prev = (fuse & 2) && c0 >= HS_PB;
+  const size_t ld = nd.ldl;
+  double* const LF = nd.LF;
+
+  __shared__ int s_pl[HS_PB];     // row (position in the front at panel start) that ends at top position c0+k
+  __shared__ int s_piv[HS_PB], s_where[HS_PB], s_what[HS_PB], s_r[HS_PB];
+  __shared__ double s_a[HS_PB][HS_PB + 1];   // L\U in pivoted order
+  __shared__ double s_n[HS_PB][HS_PB + 1];   // rows c0.. of the NEXT 32 columns as loaded (fuse & 1)
+  __shared__ double s_p[HS_PB][HS_PB + 1];   // rows c0.. of the PREVIOUS 32 columns as loaded (fuse & 2)
+  __shared__ double s_il[HS_PB][HS_PB + 1];  // inv(L), for U12
+
+  if (wave == 0) {
+    const int i = lane & 31;
+    bool alive = lane < w;
+    int pos = (lane >= w && lane < HS_PB) ? lane : -1;  // padding rows keep their place
+    double x[HS_PB];
+#pragma clang loop unroll(full)
+    for (int j = 0; j < HS_PB; ++j) x[j] = (lane < w && j < w) ? gld(LF + (size_t)(c0 + i) + (size_t)(c0 + j) * ld) : ((lane < HS_PB && i == j) ? 1.0 : 0.0);
+    bool bad = false;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < HS_PB; ++k) {
+      if (k < w) {  // wave-uniform
+        unsigned long long key = 0;
+        if (alive) key = ((unsigned long long)__double_as_longlong(fabs(x[k])) & ~0xffull) | (unsigned long long)(255 - lane);
+        const unsigned long long best = wave_max_u64(key);
+        int win;
+        double rp;
+        if ((best >> 8) != 0) {
+          win = 255 - (int)(best & 0xff);
+          rp = 1.0 / lane_bcast(x[k], win);
+        } else {  // the column is zero on every row still in play: the block is singular on its own rows -> the level is redone
+          bad = true;
+          const unsigned long long m = __ballot(alive);
+          win = m ? (__ffsll((long long)m) - 1) : 0;
+          rp = 0.0;
+        }
+        win = __builtin_amdgcn_readfirstlane(win);
+        if (lane == 0) s_pl[k] = c0 + win;
+        double l = 0.0;
+        if (alive && lane != win) {
+          l = x[k] * rp;
+          x[k] = l;
+        }
+        if (lane == win) {
+          alive = false;
+          pos = k;
+        }
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j)
+          if (j > k) x[j] = fma(-l, lane_bcast(x[j], win), x[j]);
+      } else if (lane == 0) {
+        s_pl[k] = c0 + k;
+      }
+    }
+    if (bad && lane == 0 && nd.growth) *nd.growth = 1;
+    if (pos >= 0) {
+#pragma clang loop unroll(full)
+      for (int j = 0; j < HS_PB; ++j) s_a[pos][j] = x[j];
+    }
+  } else if (wave == 1) {
+    if (w2 > 0 && lane < HS_PB) {  // lane = column of the next block
+#pragma clang loop unroll(full)
+      for (int i = 0; i < HS_PB; ++i) s_n[i][lane] = (i < w && lane < w2) ? gld(LF + (size_t)(c0 + i) + (size_t)(c0 + HS_PB + lane) * ld) : 0.0;
+    }
+  } else if (wave == 2) {
+    if (prev && lane < HS_PB) {  // lane = column of the previous block
+#pragma clang loop unroll(full)
+      for (int i = 0; i < HS_PB; ++i) s_p[i][lane] = (i < w) ? gld(LF + (size_t)(c0 + i) + (size_t)(c0 - HS_PB + lane) * ld) : 0.0;
+    }
+  } else {
+    if (lane < HS_PB) s_r[lane] = (lane < w) ? nd.rperm[c0 + lane] : 0;
+  }
+  __syncthreads();
+
+  if (wave == 0) {
+    if (lane == 0) {
+      // winners (rows by their position at panel start, in elimination order) -> LAPACK-style swaps for laswp on the other columns
+      for (int k = 0; k < HS_PB; ++k) {
+        s_where[k] = c0 + k;
+        s_what[k] = c0 + k;
+      }
+      for (int k = 0; k < w; ++k) {
+        const int r = s_pl[k];
+        const int target = c0 + k;
+        const int p = s_where[r - c0];
+        s_piv[k] = p;
+        if (p != target) {
+          const int q = s_what[k];
+          s_what[k] = r;
+          s_what[p - c0] = q;
+          s_where[r - c0] = target;
+          s_where[q - c0] = p;
+        }
+      }
+    }
+    // (same wave: the LDS writes of lane 0 are visible to the wave's later reads after the waitcnt the compiler places)
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    if (lane < w) {
+      nd.ipiv[c0 + lane] = s_piv[lane];
+      nd.rperm[c0 + lane] = s_r[s_pl[lane] - c0];
+    }
+    // the L\U block: lane -> row, two columns per pass
+    {
+      const int i = lane & 31, jh = lane >> 5;
+#pragma clang loop unroll(full)
+      for (int jj = 0; jj < HS_PB / 2; ++jj) {
+        const int j = 2 * jj + jh;
+        if (i < w && j < w) gst(LF + (size_t)(c0 + i) + (size_t)(c0 + j) * ld, s_a[i][j]);
+      }
+      if (prev) {  // pivoted rows of the previous 32 columns (the left-looking swap of the pair)
+#pragma clang loop unroll(full)
+        for (int jj = 0; jj < HS_PB / 2; ++jj) {
+          const int j = 2 * jj + jh;
+          if (i < w) gst(LF + (size_t)(c0 + i) + (size_t)(c0 - HS_PB + j) * ld, s_p[s_pl[i] - c0][j]);
+        }
+      }
+    }
+  } else if (wave == 1) {
+    // inv(L): lane i owns row i of L and of inv(L); the same row operations that reduce L to I applied to I
+    if (lane < HS_PB) {
+      const int i = lane;
+      double lr[HS_PB], il[HS_PB];
+#pragma clang loop unroll(full)
+      for (int j = 0; j < HS_PB; ++j) {
+        lr[j] = s_a[i][j];
+        il[j] = (i == j) ? 1.0 : 0.0;
+      }
+#pragma clang loop unroll(full)
+      for (int k = 0; k < HS_PB - 1; ++k) {
+        const double l = (i > k) ? lr[k] : 0.0;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j)
+          if (j <= k) il[j] = fma(-l, lane_bcast(il[j], k), il[j]);
+      }
+#pragma clang loop unroll(full)
+      for (int j = 0; j < HS_PB; ++j) {
+        gst(nd.invL + (size_t)pb * HS_PB * HS_PB + i + j * HS_PB, il[j]);
+        s_il[i][j] = il[j];
+      }
+    }
+  } else if (wave == 2) {
+    // inv(U) by back substitution in rank-1 form (zero pivots are treated as 1: the front is already flagged)
+    if (lane < HS_PB) {
+      const int i = lane;
+      double ar[HS_PB], iu[HS_PB];
+#pragma clang loop unroll(full)
+      for (int j = 0; j < HS_PB; ++j) {
+        ar[j] = s_a[i][j];
+        iu[j] = (i == j) ? 1.0 : 0.0;
+      }
+#pragma clang loop unroll(full)
+      for (int p = HS_PB - 1; p >= 0; --p) {
+        double d = lane_bcast(ar[p], p);
+        if (d == 0.0) d = 1.0;
+        const double rd = 1.0 / d;
+        const double u = (i < p) ? ar[p] : 0.0;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j) {
+          if (j >= p) {
+            if (i == p) iu[j] = iu[j] * rd;
+            const double rowp = lane_bcast(iu[j], p);
+            iu[j] = fma(-u, rowp, iu[j]);
+          }
+        }
+      }
+#pragma clang loop unroll(full)
+      for (int j = 0; j < HS_PB; ++j) gst(nd.invU + (size_t)pb * HS_PB * HS_PB + i + j * HS_PB, iu[j]);
+    }
+  }
+  if (w2 > 0) {  // U12 = inv(L11) * (P*A12) (fuse & 1), every thread four entries; inv(L) reaches LDS through wave 1
+    __syncthreads();
+    for (int e = t; e < HS_PB * HS_PB; e += 256) {
+      const int i = e & 31, j = e >> 5;
+      if (i < w && j < w2) {
+        double u = 0.0;
+        for (int q = 0; q <= i; ++q) u = fma(s_il[i][q], s_n[s_pl[q] - c0][j], u);
+        gst(LF + (size_t)(c0 + i) + (size_t)(c0 + HS_PB + j) * ld, u);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // laswp: apply swaps ipiv[k0:k1) to columns [c0, c1) of LF or UR (one column per thread)
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -550,6 +754,13 @@ void launch_tournament_round(const NodeDesc<T>* dnodes, int nbatch, int pb, int 
 template <class T>
 void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, int fuse, hipStream_t s) {
   if (nbatch <= 0) return;
+  if constexpr (sizeof(T) == 8) {
+    static const bool merged = !(getenv("HS_PANEL_OPT") && getenv("HS_PANEL_OPT")[0] == '0');  // 0: the general kernel for optimistic panels too
+    if ((fuse & 4) && merged) {
+      hipLaunchKernelGGL(panel_pivot_opt_kernel, dim3(1, nbatch), dim3(256), 0, s, dnodes, pb, fuse);
+      return;
+    }
+  }
   hipLaunchKernelGGL(panel_pivot_kernel<T>, dim3(1, nbatch), dim3(256), 0, s, dnodes, pb, fuse);
 }
 template <class T>
