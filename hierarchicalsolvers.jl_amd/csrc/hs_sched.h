@@ -302,7 +302,8 @@ struct Sched {
     static const int cap_total = env_int("HS_LA_GEMM_CAP", 448);
     // measured: helps a lone front whose panels run the tournament, hurts batches (uneven fronts) and is not needed once
     // the panel chain is short (optimistic pivoting: 520 -> 500 ms on the 32,768 root without the cap)
-    const int gcap = (cap_total > 0 && nbatch == 1 && !optimistic) ? cap_total : 0;
+    static const int cap_opt = env_int("HS_LA_CAP_OPT", 0);  // 1: cap the concurrent update of a lone front under optimistic pivoting too
+    const int gcap = (cap_total > 0 && nbatch == 1 && (!optimistic || cap_opt)) ? cap_total : 0;
     hipEvent_t ev_iter[3];
     for (auto& e : ev_iter) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     int iter = 0;

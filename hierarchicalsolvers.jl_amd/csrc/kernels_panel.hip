@@ -423,14 +423,16 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
 // panel_l21: rows below the diagonal block, one row per thread:  x <- x * inv(U11)
 // ------------------------------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int fuse) {
+__global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int fuse, int rpt) {
   __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win instruction issue over co-resident GEMM waves
   const NodeDesc<T> nd = nodes[blockIdx.y];
   const int c0 = pb * HS_PB;
   if (c0 >= nd.ni) return;
   const int w = min(HS_PB, nd.ni - c0);
   const int r0 = c0 + w;
-  if ((int)blockIdx.x * 256 >= nd.m - r0) return;
+  // rpt rows per thread, one after the other (rows t, t + 256, ... of the workgroup's 256 * rpt; HS_L21_ROWS, default 1): fewer, longer
+  // workgroups for a lone front next to a running GEMM were tried and measured no gain (launch_panel_l21)
+  if ((int)blockIdx.x * 256 * rpt >= nd.m - r0) return;
   // fuse & 1: first panel of a 64-column pair -- the thread that owns a row also applies the rank-32 update
   // A[row, next 32 columns] -= L21[row, :] * U12 (U12 left in place by panel_pivot), with L21[row, :] still in registers
   const int w2 = (fuse & 1) ? max(0, min(HS_PB, nd.ni - (c0 + HS_PB))) : 0;
@@ -444,7 +446,8 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
     }
   }
   __syncthreads();
-  const int row = r0 + blockIdx.x * 256 + threadIdx.x;
+  for (int rr = 0; rr < rpt; ++rr) {
+  const int row = r0 + (blockIdx.x * rpt + rr) * 256 + threadIdx.x;
   if (row >= nd.m) return;
   T* base = nd.LF + (size_t)row + (size_t)c0 * nd.ldl;
   T a[HS_PB];
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
       }
     }
   }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,9 +492,10 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
 // own 32 rows, so nothing outside the 32 x 32 block moves:
 //   wave 0   ONE elimination with the pivot search inside it (lane = row, implicit permutation: a row that wins step k keeps its
 //            lane and takes position k); it leaves L\U in LDS in pivoted order;
-//   then, concurrently,  wave 1: inv(L)   wave 2: inv(U)   wave 3: U12 = L^-1 * (P*A12) by forward substitution (fuse & 1)
+//   then, concurrently,  wave 1: inv(L)   wave 2: inv(U)
 //            wave 0: swaps for `laswp` (ipiv), the pivoted rows of the previous 32 columns (fuse & 2), rperm, the L\U block;
-//   the side blocks were loaded into LDS by waves 1-3 WHILE wave 0 eliminated.  One barrier, two memory round trips on the chain.
+//   and U12 = inv(L) * (P*A12) by all threads once inv(L) is in LDS (fuse & 1);
+//   the side blocks were loaded into LDS by waves 1-3 WHILE wave 0 eliminated.  Two barriers, two memory round trips on the chain.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void panel_pivot_opt_kernel(const NodeDesc<double>* __restrict__ nodes, int pb, int fuse) {
   __builtin_amdgcn_s_setprio(3);
@@ -766,7 +771,10 @@ void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, int fuse,
 template <class T>
 void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, int fuse, hipStream_t s) {
   if (nbatch <= 0 || maxrows <= 0) return;
-  hipLaunchKernelGGL(panel_l21_kernel<T>, dim3((maxrows + 255) / 256, nbatch), dim3(256), 0, s, dnodes, pb, fuse);
+  static const int rpt_env = getenv("HS_L21_ROWS") ? atoi(getenv("HS_L21_ROWS")) : 0;
+  // measured at Poisson 128^3 (tools/env_sweep.sh): 2 rows per thread for the lone fronts 3.452 s, 1 row 3.449 s, 4 rows 3.484 s -- one row stays the default
+  const int rpt = rpt_env > 0 ? rpt_env : 1;
+  hipLaunchKernelGGL(panel_l21_kernel<T>, dim3((maxrows + 256 * rpt - 1) / (256 * rpt), nbatch), dim3(256), 0, s, dnodes, pb, fuse, rpt);
 }
 template <class T>
 void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1, int k0, int k1, int maxcols, hipStream_t s) {
