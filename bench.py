@@ -437,7 +437,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, dev)
         print(json.dumps(out))
     if world > 1:
+        # release the factorization before the communicator it borrows, and that before the process group / the HIP runtime go away
+        try:
+            if getattr(S.backend, "_h", None):
+                S.backend.L.hs_free(S.backend._h)
+                S.backend._h = None
+        except NameError:
+            pass
+        torch.cuda.synchronize(dev)
         torch.distributed.barrier()
+        if libcomm is not None:
+            libcomm.close()
         torch.distributed.destroy_process_group()
 
 

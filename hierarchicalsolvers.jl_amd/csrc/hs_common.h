@@ -189,6 +189,8 @@ void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, int fuse,
 template <class T>
 void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, int fuse, hipStream_t s);
 template <class T>
+bool launch_trsm_small(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int rows, int c0, int c1, int maxcols, hipStream_t s);  // 64 / 128 rows in one launch
+template <class T>
 void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1, int k0, int k1, int maxcols, hipStream_t s);
 
 template <class T>

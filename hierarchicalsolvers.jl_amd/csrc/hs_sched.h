@@ -190,6 +190,16 @@ struct Sched {
       trsm256(mat, r0, c0, c1, nc, false);
       return;
     }
+    if (r1 - r0 == 2 * HS_PB || r1 - r0 == 4 * HS_PB) {
+      // 64 / 128 rows (the solves inside a 256-column group): one launch instead of the 3 / 7 of the recursion below
+      hipEvent_t e0 = pf->begin(s);
+      if (launch_trsm_small<T>(dn, nbatch, mat, r0, r1 - r0, c0, c1, nc, s)) {
+        pf->end(e0, HS_CAT_TRSM, s);
+        dbg("trsm_small", mat, r0, c0, c1);
+        return;
+      }
+      if (e0) (void)hipEventDestroy(e0);
+    }
     if (r1 - r0 == HS_PB) {
       // base case: multiply by the stored inverse of the 32x32 unit-lower diagonal block (MFMA GEMM, in place)
       GemmOp op{mat, mat, r0, r0 + HS_PB, c0, c1, 0, 0, 1};

@@ -749,6 +749,150 @@ __global__ __launch_bounds__(256) void laswp_kernel(const NodeDesc<T>* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// trsm_small: X[r0 : r0+32*NBLK, c0:c1) <- L[r0.., r0..]^-1 * X for the 64- and 128-row solves inside a 256-column group of lu_rec
+// (the recursion of Sched::trsm_rec turned each of them into 3 / 7 dependent launches -- 32-row inverse products and K = 32 / 64
+// sub-tile GEMMs of ~16 / ~27 us each, 13 per 256 columns of every panel chain).  One workgroup per 32 columns of X: the chunk of X, the
+// chunk of X arrives in LDS in one round trip, the stored 32 x 32 inverses and the off-diagonal blocks of L one block row ahead of their
+// use, then block forward substitution.
+// ------------------------------------------------------------------------------------------------
+template <class T, int NBLK>
+__global__ __launch_bounds__(256) void trsm_small_kernel(const NodeDesc<T>* __restrict__ nodes, int mat, int r0, int c0, int c1) {
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain
+  extern __shared__ __attribute__((aligned(16))) unsigned char trsm_small_raw[];
+  constexpr int BB = HS_PB * HS_PB;
+  // LDS budget: a chain kernel only ever finds room next to ONE resident GEMM workgroup (68 KB of the CU's 160), so the blocks of L
+  // and the inverses are staged one block row at a time from registers that were loaded a step ahead (72 KB for 128 rows of Float64)
+  T* Xs = reinterpret_cast<T*>(trsm_small_raw);  // NBLK blocks (column-major, ld 32): block row i of the chunk; becomes Y_i
+  T* Is = Xs + NBLK * BB;                        // inverse diagonal block of the current block row
+  T* Ls = Is + BB;                               // L_ik, k < i, of the current block row
+  T* Ss = Ls + (NBLK - 1) * BB;                  // its right-hand side
+  const NodeDesc<T> nd = nodes[blockIdx.y];
+  if (r0 >= nd.ni) return;
+  T* xp;
+  int ldx, xrows, xcols;
+  mat_of(nodes + blockIdx.y, mat, xp, ldx, xrows, xcols);
+  c1 = min(c1, xcols);
+  const int cc = c0 + blockIdx.x * HS_PB;
+  if (cc >= c1) return;  // workgroup-uniform
+  const int wc = min(HS_PB, c1 - cc);
+  const int wr = min(NBLK * HS_PB, nd.ni - r0);
+  const int nbv = (wr + HS_PB - 1) / HS_PB;
+  const int t = threadIdx.x;
+  const T* LF = nd.LF;
+  const size_t ldl = nd.ldl;
+  T pI[4], pL[NBLK - 1][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = t + 256 * u, a = e & 31, bcol = e >> 5;
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+      const int row = i * HS_PB + a;
+      Xs[i * BB + e] = (row < wr && bcol < wc) ? gld(xp + (size_t)(r0 + row) + (size_t)(cc + bcol) * ldx) : Scal<T>::zero();
+    }
+    pI[u] = gld(nd.invL + (size_t)(r0 / HS_PB) * BB + e);
+  }
+#pragma unroll
+  for (int i = 0; i < NBLK; ++i) {
+    if (i < nbv) {  // workgroup-uniform
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = t + 256 * u;
+        Is[e] = pI[u];
+#pragma unroll
+        for (int k = 0; k < NBLK - 1; ++k)
+          if (k < i) Ls[k * BB + e] = pL[k][u];
+      }
+      if (i + 1 < nbv) {  // the next block row's operands travel while this one is solved
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = t + 256 * u, a = e & 31, bcol = e >> 5;
+          const int row = (i + 1) * HS_PB + a;
+          pI[u] = gld(nd.invL + (size_t)(r0 / HS_PB + i + 1) * BB + e);
+#pragma unroll
+          for (int k = 0; k < NBLK - 1; ++k)
+            if (k <= i) pL[k][u] = (row < wr) ? gld(LF + (size_t)(r0 + row) + (size_t)(r0 + k * HS_PB + bcol) * ldl) : Scal<T>::zero();
+        }
+      }
+      __syncthreads();
+      T acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = Xs[i * BB + t + 256 * u];
+#pragma unroll
+      for (int k = 0; k < NBLK - 1; ++k) {
+        if (k < i) {
+          const T* Lik = Ls + k * BB;
+          const T* Yk = Xs + k * BB;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = t + 256 * u, a = e & 31, bcol = e >> 5;
+            T v = acc[u];
+#pragma unroll 8
+            for (int q = 0; q < HS_PB; ++q) v = Scal<T>::fnma(Lik[a + q * HS_PB], Yk[q + bcol * HS_PB], v);
+            acc[u] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Ss[t + 256 * u] = acc[u];
+      __syncthreads();
+      T y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = t + 256 * u, a = e & 31, bcol = e >> 5;
+        T v = Scal<T>::zero();
+#pragma unroll 8
+        for (int q = 0; q < HS_PB; ++q) v = Scal<T>::fma(Is[a + q * HS_PB], Ss[q + bcol * HS_PB], v);
+        y[u] = v;
+      }
+      __syncthreads();  // every read of Is / Ls / Ss of this block row is done before the next one restages them
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Xs[i * BB + t + 256 * u] = y[u];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = t + 256 * u, a = e & 31, bcol = e >> 5;
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+      const int row = i * HS_PB + a;
+      if (row < wr && bcol < wc) gst(xp + (size_t)(r0 + row) + (size_t)(cc + bcol) * ldx, Xs[i * BB + e]);
+    }
+  }
+}
+
+// rows = 64 or 128 (ComplexF64: 64 only -- the blocks of 128 rows would not fit the LDS); false: the caller recurses as before
+template <class T>
+bool launch_trsm_small(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int rows, int c0, int c1, int maxcols, hipStream_t s) {
+  static const bool on = !(getenv("HS_TRSM_SMALL") && getenv("HS_TRSM_SMALL")[0] == '0');
+  if (!on || nbatch <= 0 || maxcols <= 0) return false;
+  const dim3 grid((maxcols + HS_PB - 1) / HS_PB, nbatch);
+  if (rows == 2 * HS_PB) {
+    constexpr int lds = (2 + 1 + 1 + 1) * HS_PB * HS_PB * (int)sizeof(T);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)trsm_small_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((trsm_small_kernel<T, 2>), grid, dim3(256), lds, s, dnodes, mat, r0, c0, c1);
+    return true;
+  }
+  if constexpr (sizeof(T) == 8) {
+    if (rows == 4 * HS_PB) {
+      constexpr int lds = (4 + 1 + 3 + 1) * HS_PB * HS_PB * (int)sizeof(T);
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)trsm_small_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+      }
+      hipLaunchKernelGGL((trsm_small_kernel<T, 4>), grid, dim3(256), lds, s, dnodes, mat, r0, c0, c1);
+      return true;
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -787,6 +931,7 @@ void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1
   template void launch_panel_pivot<T>(const NodeDesc<T>*, int, int, int, hipStream_t);                       \
   template void launch_panel_l21<T>(const NodeDesc<T>*, int, int, int, int, hipStream_t);                    \
   template void launch_laswp<T>(const NodeDesc<T>*, int, int, int, int, int, int, int, hipStream_t);    \
+  template bool launch_trsm_small<T>(const NodeDesc<T>*, int, int, int, int, int, int, int, hipStream_t); \
 
 INST(double)
 INST(cplx)
