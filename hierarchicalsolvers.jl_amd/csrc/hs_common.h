@@ -146,6 +146,8 @@ struct GemmOp {
   int k0, k1;      // A cols = B rows (always inside [0, ni))
   int ainv;        // 1: A = invL[r0/32] (32x32), C = A*B in place on rows [r0, r0+32): the TRSM base case; 2: A = invU[r0/32];
                    // 3..6: the 256-row base case through inv256L / inv256U, as two in-place half products (resolve_op)
+                   // 7, 8: rows [r0, ..) of the 256 columns from k0 on times inv256U[k0/256], in place: the multipliers of the rows BELOW a
+                   //       256-wide diagonal block once that block is factored (Sched::lu_rec, optimistic pivoting): 7 = columns 128.. (first), 8 = columns 0..127
   int cap;         // > 0: launch at most this many workgroups per front (they walk the tiles): leaves CU slots free for a
                    // concurrent stream (the look-ahead panel chain); 0: one workgroup per tile
   int prio;        // 1: raise the waves' issue priority (s_setprio): panel work of the look-ahead side stream
@@ -159,6 +161,8 @@ struct GemmProb {
   T* C;
   int M, N, K;
   int lda, ldb, ldc;
+  int* flag = nullptr;  // optimistic pivoting: raised when a stored value of rows < flag_rows exceeds HS_GROWTH_MAX (GemmOp::ainv 7, 8: the values ARE multipliers)
+  int flag_rows = 0;
 };
 
 template <class T>
@@ -187,7 +191,7 @@ void hs_create_lookahead_streams(hipStream_t* la, hipStream_t* side_masked, hipS
 template <class T>
 void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, int fuse, hipStream_t s);
 template <class T>
-void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, int fuse, hipStream_t s);
+void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, int fuse, hipStream_t s, int rlim = HS_BIG);  // rows < rlim only
 template <class T>
 bool launch_trsm_small(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int rows, int c0, int c1, int maxcols, hipStream_t s);  // 64 / 128 rows in one launch
 template <class T>

@@ -82,6 +82,7 @@ struct Sched {
   const SolveNode<T>* sn = nullptr;  // solve descriptors of the same batch: lu_rec leaves the inverses of the 256x256 diagonal
                                      // blocks of L and U behind (TRSM base case of 256 rows; ldiv! sweeps); null = 32-row base only
   bool wide = false;                 // the descriptors carry valid inv256L / inv256U for the rows being solved
+  int rlim = HS_BIG;                 // rows the panel kernels and the in-group updates of lu_rec may touch (diagonal-block-first groups)
   bool optimistic = false;           // no tournament: every panel pivots among its own 32 rows, panel_l21 checks the multipliers
                                      // (NodeDesc::growth); the caller redoes the batch with the tournament if the flag went up
 
@@ -158,7 +159,7 @@ struct Sched {
     }
     launch_panel_pivot<T>(dn, nbatch, pb, fuse, s);
     dbg("panel_pivot", pb);
-    launch_panel_l21<T>(dn, nbatch, pb, maxm - c0, fuse, s);
+    launch_panel_l21<T>(dn, nbatch, pb, std::min(maxm, rlim) - c0, fuse, s, rlim);
     dbg("panel_l21", pb);
     pf->end(e0, HS_CAT_PANEL, s);
   }
@@ -240,8 +241,36 @@ struct Sched {
     }
     utrsm_rec(mat, r0, mid, c0, c1);
   }
+  // Optimistic pivoting never looks below the 32 rows of a diagonal block, so a 256-column group does not need the rows below ITS
+  // diagonal block until the group is done: the panel chain (pivot, L21, swaps, the 64 / 128-row solves and the K <= 128 updates) runs
+  // on the 256 x 256 block alone -- every kernel of it one workgroup, which finds a slot next to a running GEMM at once, where the
+  // 128-workgroup L21 step of a 32,768-row front waited ~80 us for its slots -- and the multipliers of all rows below follow as
+  // L_below = A_below * inv(U_group): two in-place MFMA products with the stored inverse of the group's U (GemmOp::ainv 7, 8), which
+  // also check the growth bound of the rows partial pivoting could have picked.  Float64 only (the complex tile is 64 columns wide: the
+  // in-place product would need three passes); the tournament path keeps the full-height panels.
+  bool diag_first() const {
+    static const int on = env_int("HS_DIAG_FIRST", 1);
+    return on && optimistic && sn && sizeof(T) == 8 && rlim == HS_BIG;
+  }
   void lu_rec(int c0, int c1) {
     if (c0 >= maxni) return;
+    if (c1 - c0 == 256 && diag_first()) {
+      rlim = c0 + 256;
+      lu_rec_inner(c0, c1);
+      rlim = HS_BIG;
+      launch_inv256<T>(sn, nbatch, maxni, s, c0 / 256);
+      const int r0 = c0 + 256;
+      if (r0 < maxm) {
+        for (int code : {7, 8}) {
+          GemmOp op{HS_MAT_LF, HS_MAT_LF, r0, HS_BIG, c0, c1, c0, c1, code, 0, hiprio};
+          hipEvent_t e0 = pf->begin(s);
+          launch_gemm_op<T>(dn, nbatch, maxm - r0, 128, op, s);
+          pf->end(e0, HS_CAT_TRSM, s);
+          dbg("l_below", c0, r0, code);
+        }
+      }
+      return;
+    }
     lu_rec_inner(c0, c1);
     if (sn && c1 - c0 == 256) launch_inv256<T>(sn, nbatch, maxni, s, c0 / 256);  // the block is final: leave its inverses behind
   }
@@ -263,7 +292,7 @@ struct Sched {
     if (mid < maxni) {
       laswp(HS_MAT_LF, mid, c1, c0, mid);
       trsm_rec(HS_MAT_LF, c0, mid, mid, c1);
-      gemm(HS_MAT_LF, HS_MAT_LF, mid, HS_BIG, mid, c1, c0, mid);
+      gemm(HS_MAT_LF, HS_MAT_LF, mid, rlim, mid, c1, c0, mid);
       lu_rec(mid, c1);
       laswp(HS_MAT_LF, c0, mid, mid, c1);
     }

@@ -62,6 +62,27 @@ __device__ inline bool resolve_op(const NodeDesc<T>* pn, const GemmOp& op, GemmP
   mat_of(pn, op.bmat, bp, ldb, brows, bcols);
   const int ni = pn->ni, ldl = pn->ldl;
   T* const LF = pn->LF;
+  if (op.ainv >= 7) {
+    // L[r0.., k0 : k0+wl) <- A[r0.., k0 : k0+wl) * inv(U[k0 : k0+wl, k0 : k0+wl)), in place as two products that read every column they
+    // overwrite before their stores (one tile column each: N <= 128): 7 = columns 128.. from all wl columns (first), 8 = columns 0..127
+    const int wl = min(256, ni - op.k0);
+    const int M = min(op.r1, crows) - op.r0;
+    if (wl <= 0 || M <= 0) return false;
+    const T* V = pn->inv256U + (size_t)(op.k0 / 256) * 65536;
+    T* X = LF + (size_t)op.r0 + (size_t)op.k0 * ldl;
+    if (op.ainv == 7) {
+      if (wl <= 128) return false;
+      p.A = X; p.B = V + (size_t)128 * 256; p.C = X + (size_t)128 * ldl;
+      p.M = M; p.N = wl - 128; p.K = wl;
+    } else {
+      p.A = X; p.B = V; p.C = X;
+      p.M = M; p.N = min(128, wl); p.K = min(128, wl);
+    }
+    p.lda = ldl; p.ldb = 256; p.ldc = ldl;
+    p.flag = pn->growth;
+    p.flag_rows = pn->pivrows - op.r0;
+    return true;
+  }
   if (op.ainv >= 3) {
     // 256-row TRSM base case X[r0:r0+256, c0:c1) <- inv256 * X, in place, as two half products that never read a row
     // another workgroup may already have overwritten (each has one tile row and reads all of K before its stores):
@@ -276,7 +297,11 @@ __device__ inline void gemm_tile_d(const GemmProb<double>& p, int tile_m, int ti
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int nn = n0 + wn * 64 + j * 16 + l4 + 4 * r;
-        if (rok && nn < N) gst(C + (size_t)mm + (size_t)nn * p.ldc, minus ? (cv[j][r] - acc[i][j][r]) : acc[i][j][r]);
+        if (rok && nn < N) {
+          const double v = minus ? (cv[j][r] - acc[i][j][r]) : acc[i][j][r];
+          gst(C + (size_t)mm + (size_t)nn * p.ldc, v);
+          if (p.flag && mm < p.flag_rows && !(fabs(v) <= HS_GROWTH_MAX)) *p.flag = 1;  // uniform null test; NaN counts
+        }
       }
   }
 }

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void panel_pivot_kernel(const NodeDesc<T>* __r
 // panel_l21: rows below the diagonal block, one row per thread:  x <- x * inv(U11)
 // ------------------------------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int fuse, int rpt) {
+__global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __restrict__ nodes, int pb, int fuse, int rpt, int rlim) {
   __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win instruction issue over co-resident GEMM waves
   const NodeDesc<T> nd = nodes[blockIdx.y];
   const int c0 = pb * HS_PB;
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
   const int r0 = c0 + w;
   // rpt rows per thread, one after the other (rows t, t + 256, ... of the workgroup's 256 * rpt; HS_L21_ROWS, default 1): fewer, longer
   // workgroups for a lone front next to a running GEMM were tried and measured no gain (launch_panel_l21)
-  if ((int)blockIdx.x * 256 * rpt >= nd.m - r0) return;
+  const int mrows = min(nd.m, rlim);  // rlim: only the rows of the 256-wide diagonal block (Sched::lu_rec, the rows below follow as one product)
+  if ((int)blockIdx.x * 256 * rpt >= mrows - r0) return;
   // fuse & 1: first panel of a 64-column pair -- the thread that owns a row also applies the rank-32 update
   // A[row, next 32 columns] -= L21[row, :] * U12 (U12 left in place by panel_pivot), with L21[row, :] still in registers
   const int w2 = (fuse & 1) ? max(0, min(HS_PB, nd.ni - (c0 + HS_PB))) : 0;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
   __syncthreads();
   for (int rr = 0; rr < rpt; ++rr) {
   const int row = r0 + (blockIdx.x * rpt + rr) * 256 + threadIdx.x;
-  if (row >= nd.m) return;
+  if (row >= mrows) return;
   T* base = nd.LF + (size_t)row + (size_t)c0 * nd.ldl;
   T a[HS_PB];
 #pragma unroll
@@ -913,12 +914,12 @@ void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, int fuse,
   hipLaunchKernelGGL(panel_pivot_kernel<T>, dim3(1, nbatch), dim3(256), 0, s, dnodes, pb, fuse);
 }
 template <class T>
-void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, int fuse, hipStream_t s) {
+void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows, int fuse, hipStream_t s, int rlim) {
   if (nbatch <= 0 || maxrows <= 0) return;
   static const int rpt_env = getenv("HS_L21_ROWS") ? atoi(getenv("HS_L21_ROWS")) : 0;
   // measured at Poisson 128^3 (tools/env_sweep.sh): 2 rows per thread for the lone fronts 3.452 s, 1 row 3.449 s, 4 rows 3.484 s -- one row stays the default
   const int rpt = rpt_env > 0 ? rpt_env : 1;
-  hipLaunchKernelGGL(panel_l21_kernel<T>, dim3((maxrows + 256 * rpt - 1) / (256 * rpt), nbatch), dim3(256), 0, s, dnodes, pb, fuse, rpt);
+  hipLaunchKernelGGL(panel_l21_kernel<T>, dim3((maxrows + 256 * rpt - 1) / (256 * rpt), nbatch), dim3(256), 0, s, dnodes, pb, fuse, rpt, rlim);
 }
 template <class T>
 void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1, int k0, int k1, int maxcols, hipStream_t s) {
@@ -929,7 +930,7 @@ void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1
 #define INST(T)                                                                                         \
   template void launch_tournament_round<T>(const NodeDesc<T>*, int, int, int, int, hipStream_t);        \
   template void launch_panel_pivot<T>(const NodeDesc<T>*, int, int, int, hipStream_t);                       \
-  template void launch_panel_l21<T>(const NodeDesc<T>*, int, int, int, int, hipStream_t);                    \
+  template void launch_panel_l21<T>(const NodeDesc<T>*, int, int, int, int, hipStream_t, int);               \
   template void launch_laswp<T>(const NodeDesc<T>*, int, int, int, int, int, int, int, hipStream_t);    \
   template bool launch_trsm_small<T>(const NodeDesc<T>*, int, int, int, int, int, int, int, hipStream_t); \
 
