@@ -340,8 +340,8 @@ def _worker_dist(rank, world, port, name, q):
         q.put((rank, "ERR " + repr(e) + traceback.format_exc(), 0))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("name", [((17, 13), "poisson", 12), ((8, 8, 6), "helmholtz", 30)])
+@pytest.mark.parametrize("world,name", [(2, ((17, 13), "poisson", 12)), (4, ((17, 13), "poisson", 12)), (2, ((8, 8, 6), "helmholtz", 30)),
+                                        (4, ((8, 8, 6), "helmholtz", 30)), (8, ((33, 29), "poisson", 12))])
 def test_group_fronts_over_gloo(world, name):
     """dist_top: replicated fronts above the cut, pairwise swaps at the joins, no communication in the backward sweep."""
     import torch.multiprocessing as mp
