@@ -140,9 +140,13 @@ int hs_ldiv_dev_z(hs_handle* F, double* dC, int64_t ldc, const double* dB, int64
  * every input resident in HBM; the pattern (colptr, rowval, tree) is reused for new values of A.
  * rank / nranks (a power of two): with nranks > 1 the 2^p subtrees rooted at tree level p+1 go one per rank
  * (factorization.jl:20-21 factors them one after the other; they are independent), and a front above the cut
- * is eliminated by the first rank of its group.  The library moves no data between ranks: the host layer does,
- * with its own communication library (torch.distributed / RCCL here, MPI.jl for a Julia host), using
- * hs_exchange_info for WHAT crosses ranks and hs_set_schur_buffer / hs_pack_bnd / hs_unpack_bnd for WHERE. */
+ * is eliminated by the first rank of its group (hs_options.dist_top = 0) or by all ranks of its group (dist_top = 1).
+ *   dist_top = 0: the library moves no data between ranks: the host layer does, with its own communication library
+ *     (torch.distributed / RCCL here, MPI.jl for a Julia host), using hs_exchange_info for WHAT crosses ranks and
+ *     hs_set_schur_buffer / hs_pack_bnd / hs_unpack_bnd for WHERE, and drives hs_numeric_levels / hs_solve_*_levels level by level.
+ *   dist_top = 1: the library moves everything through the communicator given with hs_set_comm (below): one
+ *     hs_numeric_levels(F, nlevels, 0) factors, hs_ldiv_* / hs_ldiv_dev_* solve (every rank passes the same right-hand side and
+ *     receives the whole solution). */
 int hs_analyze(int is_complex, int64_t n, const int64_t* colptr, const int64_t* rowval, const hs_tree* tree,
                const hs_options* opts, int64_t rank, int64_t nranks, hs_handle** out);
 /* Host-side plan only (ownership, exchange list, sizes): touches no device, for schedule tests and sizing. */
