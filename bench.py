@@ -265,7 +265,15 @@ def main():
                                       f"point-to-point rate {p2p_gbps:.1f} GB/s below --dist-min-gbps {args.dist_min_gbps:g}")
             libcomm = None
     t0 = time.perf_counter()
-    S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, libcomm=libcomm, **fopts)
+    try:
+        S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, libcomm=libcomm, **fopts)
+    except Exception as e:  # noqa: BLE001 -- the plan refuses the group fronts (e.g. a branch of the tree ends above the rank cut): same decision on every rank
+        if not fopts.get("dist_top"):
+            raise
+        dist_note = f"dist_top refused by the plan: {e}"
+        fopts.pop("dist_top")
+        libcomm = None
+        S = hsdist.StagedSolver(Ap, nd, nd_loc, rank=rank, nranks=world, device=dev, **fopts)
     torch.cuda.synchronize(dev)
     t_analyze = time.perf_counter() - t0  # hs_analyze: pattern upload, descriptors, hipMalloc of the factor arena (once per pattern)
     b_dev0 = torch.from_numpy(np.ascontiguousarray(bp)).to(dev)

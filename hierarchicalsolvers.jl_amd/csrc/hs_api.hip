@@ -465,6 +465,9 @@ static void build_plan(hs_handle* h, int64_t n, const hs_tree* tr, const SplitTr
       x.mine = x.dist ? (h->rank >= x.glo && h->rank < x.glo + x.gcnt) : (x.owner == h->rank);
       if (x.level == 0 && h->opts.dist_top && h->nranks > 1)
         HS_FAIL(HS_ERR_UNSUPPORTED, i, "hs_options.dist_top with a root that keeps a boundary (|root.bnd| = %d)", x.ni);
+      if (x.dist && x.leaf)  // a branch of the tree ends above the rank cut: its group would have nothing to join
+        HS_FAIL(HS_ERR_UNSUPPORTED, i, "hs_options.dist_top: node %d is a leaf at level %d, above the rank cut of %d ranks (level %d); use fewer ranks or dist_top = 0", i,
+                x.level, h->nranks, h->cut_level);
       if (!x.leaf && x.level >= 1) {
         if (x.right < 0) {  // later slice of a split front (single-rank plans only): same ranks as its only child
           lo[x.left] = lo[i];

@@ -386,3 +386,22 @@ def test_dist_top_plan_matches_library(hs):
                 assert sorted(got) == sorted(want)
             finally:
                 L.hs_free(h)
+
+
+def test_dist_top_rejects_a_tree_that_ends_above_the_cut(hs):
+    """A branch that ends above the rank cut leaves its group with nothing to join: refused with the plan (dist_top = 0 still accepts it)."""
+    from helpers import prepare
+
+    P = prepare(hs, (9, 7), kind="poisson", nmax=40)  # a shallow tree
+    L = hs._lib.lib()
+    depth = None
+    h = hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=1)
+    try:
+        depth = L.hs_nlevels(h)
+    finally:
+        L.hs_free(h)
+    world = 1 << depth  # more ranks than the shortest branch has levels
+    with pytest.raises(hs._lib.Unsupported if hasattr(hs._lib, "Unsupported") else Exception, match="above the rank cut"):
+        hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=world, dist_top=True)
+    h = hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=world)
+    L.hs_free(h)
