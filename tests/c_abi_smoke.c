@@ -45,6 +45,26 @@ static int (*p_hs_symbolic_from_graph)(int64_t, const int64_t*, const int64_t*, 
 static const int64_t* (*p_hs_symbolic_perm)(const hs_symbolic*);
 static int (*p_hs_symbolic_tree)(const hs_symbolic*, hs_tree*);
 static void (*p_hs_symbolic_free)(hs_symbolic*);
+static int (*p_hs_comm_unique_id)(void*);
+static int (*p_hs_comm_create_rccl)(const void*, int64_t, int64_t, hs_comm**);
+static int (*p_hs_comm_create_host)(hs_transfer_fn, void*, int64_t, int64_t, hs_comm**);
+static void (*p_hs_comm_free)(hs_comm*);
+static const char* (*p_hs_comm_kind)(const hs_comm*);
+static int (*p_hs_comm_selftest)(hs_comm*, int64_t);
+static int (*p_hs_set_comm)(hs_handle*, hs_comm*);
+
+/* hs_transfer_fn of a one-rank host: the only peer is the rank itself -- every send is the matching receive */
+static int self_transfer(void* user, int64_t nsend, const int64_t* send_peer, void* const* send_buf, const int64_t* send_bytes, int64_t nrecv,
+                         const int64_t* recv_peer, void* const* recv_buf, const int64_t* recv_bytes) {
+  int64_t* calls = (int64_t*)user;
+  ++*calls;
+  if (nsend != nrecv) return 1;
+  for (int64_t k = 0; k < nsend; ++k) {
+    if (send_peer[k] != 0 || recv_peer[k] != 0 || send_bytes[k] != recv_bytes[k]) return 2;
+    memcpy(recv_buf[k], send_buf[k], (size_t)send_bytes[k]);
+  }
+  return 0;
+}
 
 /* 5-point Helmholtz on an N x N grid, CSC, 1-based: A = -Laplace_h - k^2 + i*sigma (complex symmetric, not Hermitian) */
 static void build_matrix(int N, int64_t** colptr, int64_t** rowval, double complex** nz) {
@@ -131,6 +151,7 @@ int main(int argc, char** argv) {
   LOAD(hs_options_default); LOAD(hs_factor_z); LOAD(hs_factor_d); LOAD(hs_ldiv_z); LOAD(hs_ldiv_d); LOAD(hs_maxrank); LOAD(hs_is_complex);
   LOAD(hs_size); LOAD(hs_free); LOAD(hs_last_error); LOAD(hs_device_info); LOAD(hs_symbolic_from_graph); LOAD(hs_symbolic_perm);
   LOAD(hs_symbolic_tree); LOAD(hs_symbolic_free);
+  LOAD(hs_comm_unique_id); LOAD(hs_comm_create_rccl); LOAD(hs_comm_create_host); LOAD(hs_comm_free); LOAD(hs_comm_kind); LOAD(hs_comm_selftest); LOAD(hs_set_comm);
 
   /* the option struct crosses the ABI with the reference's defaults (HierarchicalSolvers.jl:43-54) */
   hs_options o;
@@ -241,6 +262,33 @@ int main(int argc, char** argv) {
     free(r);
   }
   const double res_d = sqrt(nr / nb);
+  /* the communicator part of the ABI ("Multi-GPU hosts") from C, at one rank: the host-staged transport through a C
+   * callback, the RCCL transport from a fresh id; both must pass the library's self-test and attach to the handle */
+  {
+    hs_comm* hc = NULL;
+    int64_t calls = 0;
+    st = p_hs_comm_create_host(self_transfer, &calls, 0, 1, &hc);
+    if (st != HS_OK || !hc || strcmp(p_hs_comm_kind(hc), "host") != 0 || p_hs_comm_selftest(hc, 100000) != HS_OK || calls < 1 || p_hs_set_comm(F, hc) != HS_OK) {
+      fprintf(stderr, "host-staged communicator: %d '%s' (callback ran %lld times)\n", st, p_hs_last_error(), (long long)calls);
+      return 1;
+    }
+    p_hs_set_comm(F, NULL);
+    p_hs_comm_free(hc);
+    unsigned char id[128];
+    hs_comm* rc = NULL;
+    st = p_hs_comm_unique_id(id);
+    if (st == HS_OK) st = p_hs_comm_create_rccl(id, 0, 1, &rc);
+    if (st != HS_OK || !rc || strcmp(p_hs_comm_kind(rc), "rccl") != 0 || p_hs_comm_selftest(rc, 1 << 20) != HS_OK) {
+      fprintf(stderr, "RCCL communicator: %d '%s'\n", st, p_hs_last_error());
+      return 1;
+    }
+    hs_comm* bad = NULL;
+    if (p_hs_comm_create_rccl(id, 3, 2, &bad) != HS_ERR_ARGUMENT || bad != NULL) {  /* rank outside 0:nranks-1 */
+      fprintf(stderr, "hs_comm_create_rccl accepted rank 3 of 2\n");
+      return 1;
+    }
+    p_hs_comm_free(rc);
+  }
   p_hs_free(F);
   p_hs_symbolic_free(S);
   printf("C_ABI_SMOKE %s n=%lld arch=%s cus=%lld  residual z=%.2e d=%.2e\n", (worst < 1e-10 && res_d < 1e-10) ? "OK" : "FAIL", (long long)n, arch,
