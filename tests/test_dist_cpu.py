@@ -405,3 +405,60 @@ def test_dist_top_rejects_a_tree_that_ends_above_the_cut(hs):
         hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=world, dist_top=True)
     h = hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=world)
     L.hs_free(h)
+
+
+def _worker_transfer(rank, world, port, q):
+    try:
+        import ctypes as C
+
+        import torch  # noqa: F401
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hsamd
+
+        hs = hsamd.load()
+        from hierarchicalsolvers_jl_amd.dist import LibComm
+
+        # what the library hands to hs_transfer_fn: one host message per peer and direction (here: to / from every other rank, sizes differ per pair)
+        peers = [r for r in range(world) if r != rank]
+        sbufs = [np.full(1000 + 10 * rank + p, 16 * rank + p, dtype=np.uint8) for p in peers]
+        rbufs = [np.zeros(1000 + 10 * p + rank, dtype=np.uint8) for p in peers]
+        n = len(peers)
+        i64 = C.c_int64
+        speer = (i64 * n)(*peers)
+        sbytes = (i64 * n)(*[b.size for b in sbufs])
+        rbytes = (i64 * n)(*[b.size for b in rbufs])
+        sptr = (C.c_void_p * n)(*[b.ctypes.data for b in sbufs])
+        rptr = (C.c_void_p * n)(*[b.ctypes.data for b in rbufs])
+        st = LibComm._transfer(None, n, speer, sptr, sbytes, n, speer, rptr, rbytes)
+        ok = st == 0 and all(np.all(rbufs[k] == 16 * p + rank) for k, p in enumerate(peers))
+        st0 = LibComm._transfer(None, 0, speer, sptr, sbytes, 0, speer, rptr, rbytes)  # nothing to move
+        q.put((rank, bool(ok and st0 == 0)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "ERR " + repr(e) + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_transfer_callback_over_gloo(world):
+    """The Python half of the host-staged communicator (`LibComm._transfer`, the hs_transfer_fn the library calls with host pointers):
+    every rank exchanges one message of its own size with every other rank in a single call."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 5 + world * 31 + 407) % 2000
+    procs = [ctx.Process(target=_worker_transfer, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok in sorted(res):
+        assert ok is True, (rank, ok)
