@@ -202,7 +202,8 @@ def main():
     ap.add_argument("--mf", nargs="?", const=1, default=0, type=int, help="matrix-free compressed branch: S travels between the compressed fronts as HSS matrices (the reference's data flow); 1 = interior blocks of those fronts dense (unless --hss-min), 2 = one HSS matrix, 3 = the reference's 2x2 block factorization over HSS blocks")
     ap.add_argument("--dist-top", type=int, default=-1, help="N > 1: fronts above the rank cut eliminated by their whole group of ranks (csrc/hs_dist.h, RCCL inside the library); "
                     "-1 = on for exact runs when the library's communicator passes its self-test on every rank, 0 = off (subtree-per-rank only: the group's first rank eliminates them)")
-    ap.add_argument("--dist-min-gbps", type=float, default=12.0, help="--dist-top -1: minimum measured point-to-point rate (ring shift of 128 MiB through the library's communicator, slowest rank)")
+    ap.add_argument("--dist-min-gbps", type=float, default=25.0, help="--dist-top -1: minimum measured point-to-point rate (ring shift of 128 MiB through the library's communicator, slowest rank); below ~25 GB/s the block-column "
+                    "messages of a 32,768 front (4.3 GB of L parts on the critical path of 2 ranks) cost more than the second rank's share of the trailing updates gains (DESIGN.md section 6)")
     ap.add_argument("--leafsize", type=int, default=32, help="SolverOptions.leafsize (HSS leaves; the device uses at least 128)")
     args = ap.parse_args()
 
