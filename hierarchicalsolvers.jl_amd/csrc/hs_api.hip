@@ -760,7 +760,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
       HS_HIP(hipStreamCreate(&h->stream_comm));
       dmalloc((void**)&h->d_gflags, (size_t)nranks * sizeof(int), "group flags");
       size_t stage = 0;
-      const int dist_nb = Sched<T>::env_int("HS_DIST_NB", 1024);
+      const int dist_nb = Sched<T>::env_int("HS_DIST_NB", 512);
       for (int i = 0; i < h->nnodes; ++i)
         if (N[i].dist && N[i].mine) stage = std::max(stage, dist_stage_elems(N[i].ldl, N[i].ni, std::max(dist_nb, 256), sizeof(T)));
       if (stage > 0) {
@@ -1033,11 +1033,11 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     if (dx) {
       if (!h->comm) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_options.dist_top needs a communicator (hs_set_comm) before hs_numeric_levels");
       hipStream_t sc = h->stream_comm;
-      static const int dist_nb = Sched<T>::env_int("HS_DIST_NB", 1024);
+      static const int dist_nb = Sched<T>::env_int("HS_DIST_NB", 512);
       if (dist_nb < 256 || (dist_nb & (dist_nb - 1))) HS_FAIL(HS_ERR_ARGUMENT, dist_nb, "ArgumentError: HS_DIST_NB = %d must be a power of two >= 256", dist_nb);
       const size_t nblk32 = (dx->ni + HS_PB - 1) / HS_PB;
       T* dinv = (T*)h->d_inv;
-      static const int dist_period = std::max(1, Sched<T>::env_int("HS_DIST_PERIOD", 1));
+      static const int dist_period = std::max(1, Sched<T>::env_int("HS_DIST_PERIOD", 2));
       DF = DistFront<T>{h->comm, dx->glo, dx->gcnt, h->rank, dist_nb, dist_period, sc, dx->ni, dx->nb, dx->m, dx->ldl, dx->ldu, dx->lds,
                         dfac + dx->off_LF, dfac + dx->off_UR, dsb + dx->off_SB, dinv + dx->off_inv, dinv + dx->off_inv + nblk32 * HS_PB * HS_PB,
                         dinv + dx->off_inv256, dinv + dx->off_inv256 + (size_t)((dx->ni + 255) / 256) * 65536, h->d_int + dx->off_ipiv,

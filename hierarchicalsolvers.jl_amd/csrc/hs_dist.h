@@ -192,12 +192,18 @@ static void factor_front_dist(Sched<T>& base, const DistFront<T>& D) {
       HS_HIP(hipEventRecord(ev_have[j + 1], sc));
       dist_bcast_upper(D, j + 1, sc);  // behind the critical message: it travels while the next block column is being factored
     }
-    for (int k = j + (next_mine ? 2 : 1); k < nblk; ++k) {  // my other block columns
-      if (!mine(k)) continue;
-      const int k0 = k * NB, k1 = k0 + NB;
+    for (int k = j + (next_mine ? 2 : 1); k < nblk;) {  // my other block columns, one launch group per run of consecutive ones
+      if (!mine(k)) {
+        ++k;
+        continue;
+      }
+      int ke = k;
+      while (ke < nblk && mine(ke)) ++ke;
+      const int k0 = k * NB, k1 = ke * NB;
       mn.laswp(HS_MAT_LF, k0, k1, c0, c1);
       mn.trsm_rec(HS_MAT_LF, c0, c1, k0, k1);
       mn.gemm(HS_MAT_LF, HS_MAT_LF, c1, HS_BIG, k0, k1, c0, c1);
+      k = ke;
     }
     if (b1 > b0) {  // my slice of the boundary columns
       mn.laswp(HS_MAT_UR, b0, b1, c0, c1);

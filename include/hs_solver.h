@@ -83,7 +83,7 @@ typedef struct hs_options {
   uint8_t dist_top;   /* multi-rank factorizations (nranks > 1): 1 = every front ABOVE the rank cut is eliminated by all ranks of its group instead of
                          the group's first rank (the reference factors the two subtrees of a node one after the other although they are independent,
                          src/factorization.jl:20-21; above the cut the independent units are the block columns of one front): block columns of
-                         HS_DIST_NB (1024) interior DOFs dealt round-robin over the group, each factored by its owner and fanned out to the group,
+                         HS_DIST_NB (512) interior DOFs dealt over the group in runs of HS_DIST_PERIOD (2), each factored by its owner and fanned out to the group,
                          every rank updating its own block columns and its slice of the boundary columns; the group ends holding the complete
                          factors and Schur complement, sibling groups swap Schur complements pairwise at the join.  Needs a communicator
                          (hs_set_comm).  Fronts above the cut are eliminated exactly in this mode (no compression there). */

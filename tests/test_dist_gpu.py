@@ -121,7 +121,7 @@ def test_two_ranks_compressed_fronts():
 
 @pytest.mark.parametrize("world,name,nb,period", [(2, "poisson3d_32", 256, 1), (4, "poisson3d_32", 256, 1), (2, "helmholtz3d_32", 256, 1),
                                                   (4, "helmholtz2d_p1_h64_nmax100", 256, 1), (2, "poisson3d_32", 1024, 1), (2, "poisson3d_64", 1024, 1),
-                                                  (2, "poisson3d_32", 256, 2), (2, "poisson3d_64", 256, 4)])
+                                                  (2, "poisson3d_32", 256, 2), (2, "poisson3d_64", 256, 4), (2, "poisson3d_64", 512, 2), (4, "poisson3d_64", 512, 2)])
 def test_group_fronts_one_gpu(world, name, nb, period):
     """hs_options.dist_top: the fronts above the rank cut are eliminated by all ranks of their group (csrc/hs_dist.h) -- block columns of
     HS_DIST_NB interior DOFs dealt round-robin, factored by their owner, fanned out, boundary-column slices gathered at the end -- through
