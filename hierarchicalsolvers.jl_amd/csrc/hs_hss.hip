@@ -550,6 +550,33 @@ void fill_randn(T* out, int rows, int ld, int cols, uint64_t seed, hipStream_t s
   hipLaunchKernelGGL(hss_randn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (double*)out, rows * f, ld * f, cols, seed);
 }
 
+// Largest row 2-norm of a block of samples: the scale of what the products summed up BEFORE a node's own block is subtracted from its rows --
+// round-off of that scale is what the residual norms of the orthogonalisation bottom out at, whatever tolerance is asked for.
+template <class T>
+__global__ __launch_bounds__(256) void rownorm_max_kernel(const T* __restrict__ Y, int ld, int rows, int cols, unsigned long long* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.0;
+  if (i < rows)
+    for (int c = 0; c < cols; ++c) {
+      const double a = Scal<T>::abs1(Y[(size_t)i + (size_t)c * ld]);
+      acc += a * a;
+    }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + w]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(sqrt(red[0])));  // non-negative doubles order like their bit patterns
+}
+// HS_NOISE_REL * (that scale): candidates whose residual norm is below it are round-off, not rank (abs1 of a complex entry is |re| + |im|: within sqrt(2))
+#define HS_NOISE_REL 1e-13
+static double noise_rel() {
+  static const double v = getenv("HS_NOISE_REL") ? atof(getenv("HS_NOISE_REL")) : HS_NOISE_REL;  // diagnostics
+  return v;
+}
+
 template <class T>
 void build_tree(HssT<T>& H, int n, int leafsize, int first_split) {
   H.nd.clear();
@@ -624,6 +651,8 @@ struct CholJob {
   int* nacc;     // out: b'
   double atol, rtol, scale_floor;
   int b, first;
+  double floor_abs;  // nothing below this is accepted: the round-off level of the block's samples (0: none)
+  double cond, noise_rel;  // HS_CHOL_COND, HS_NOISE_REL (run-time copies: diagnostics may override them)
 };
 template <class T>
 __device__ inline double real_of(T a);
@@ -642,7 +671,7 @@ __device__ inline cplx from_real<cplx>(double a) { return {a, 0.0}; }
 // and only a well-conditioned prefix is ACCEPTED -- d_k above the truncation threshold and above 1e-5 of the block's first pivot (what a
 // Gram matrix resolves reliably in double precision is d_k / |w_k| >~ 1e-8).  Rejected candidates stay next in line: the following
 // window orthogonalises them against the rows accepted here before judging them again.
-#define HS_CHOL_COND 1e-5
+#define HS_CHOL_COND 1e-2
 #define HS_QW 64  // candidates per window (rows orthogonalised per step): one wave factors their HS_QW x HS_QW Gram matrix in LDS
 template <class T>
 __global__ __launch_bounds__(64) void chol_block_kernel(const CholJob<T>* __restrict__ jobs) {
@@ -679,9 +708,9 @@ __global__ __launch_bounds__(64) void chol_block_kernel(const CholJob<T>* __rest
     if (k == 0) {
       d0 = dk;
       if (j.first) top = dk;
-      tau = fmax(j.atol, j.rtol * fmax(top, j.scale_floor));
+      tau = fmax(fmax(j.atol, j.rtol * fmax(top, j.scale_floor)), fmax(j.floor_abs, j.noise_rel * top));
     }
-    if (!(dk > tau) || !(dk > HS_CHOL_COND * d0) || !(dk > 0.0)) break;  // uniform: every thread sees the same dk
+    if (!(dk > tau) || !(dk > j.cond * d0) || !(dk > 0.0)) break;  // uniform: every thread sees the same dk
     // symmetric swap k <-> pv of the full square copy (both triangles are maintained) and of the finished columns
     if (pv != k && t < b) {
       if (t == 0) { const int q = perm[k]; perm[k] = perm[pv]; perm[pv] = q; }
@@ -756,6 +785,7 @@ struct QrJob {
   int* p;         // device: candidate order of the rows (m entries; the pivot order of a tournament-pivoted LU), re-ordered in place
   int rmax;       // candidates: the first rmax rows of p
   double atol_scale = 1.0;  // the absolute tolerance is multiplied by this (rows of an un-normalised Gaussian sketch are sqrt(k) times longer)
+  double floor_abs = 0.0;   // round-off level of the rows of M (absolute): candidates below it are noise whatever the tolerance says
   // results
   int r = 0;
   double top = 0.0;      // d_0
@@ -812,6 +842,7 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
   std::vector<SubJob<T>> subs;
   std::vector<GemmProb<T>> g;
   std::vector<std::vector<T*>> linv(nj), linvp(nj);  // one 32 x 32 slot per accepted block
+  static const double chol_cond = getenv("HS_CHOL_COND") ? atof(getenv("HS_CHOL_COND")) : HS_CHOL_COND;  // diagnostics
   static const bool qtime = getenv("HS_QR_TIMING") != nullptr;  // diagnostics: wall time of the phases (adds nothing: every step syncs anyway)
   auto tq0 = std::chrono::steady_clock::now();
   int nsteps = 0;
@@ -852,7 +883,7 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       linv[a].push_back(slot);
       linvp[a].push_back(slot + HS_QW * HS_QW);
       cj.push_back(CholJob<T>{S.G, S.L + S.done + (size_t)S.done * S.ldl, S.ldl, slot, slot + HS_QW * HS_QW, S.d + S.done, S.top, J.p + S.done, S.lperm, S.nacc, atol * J.atol_scale,
-                              rtol, scale_floor, b, S.done == 0 ? 1 : 0});
+                              rtol, scale_floor, b, S.done == 0 ? 1 : 0, J.floor_abs, chol_cond, noise_rel()});
     });
     run_gemms(tmp, g, 0, s);
     CholJob<T>* dcj = upload(tmp, cj, s);
@@ -909,6 +940,19 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
   HSS_HIP(hipStreamSynchronize(s));
   for (int a = 0; a < nj; ++a)
     if (jobs[a].r == 0) jobs[a].top = std::max(jobs[a].top, 0.0);
+  static const bool qdebug = getenv("HS_QR_DEBUG") != nullptr;  // diagnostics: the accepted d_j of the job of largest rank, window by window
+  if (qdebug) {
+    int am = 0;
+    for (int a = 1; a < nj; ++a)
+      if (jobs[a].r > jobs[am].r) am = a;
+    const QrJob<T>& J = jobs[am];
+    std::vector<double> hd((size_t)std::max(J.r, 1));
+    if (J.r > 0) HSS_HIP(hipMemcpy(hd.data(), st[am].d, sizeof(double) * (size_t)J.r, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[hs qr debug] %d jobs; job %d: m %d q %d rmax %d -> r %d, top %.3e, tau_abs %.3e tau_rel %.3e floor %.3e; windows (offset:width d_first..d_last):", nj, am, J.m, J.q, J.rmax, J.r, J.top,
+            atol * J.atol_scale, rtol * J.top, J.floor_abs);
+    for (auto& b : st[am].blocks) fprintf(stderr, " %d:%d %.2e..%.2e", b.first, b.second, hd[b.first], hd[b.first + b.second - 1]);
+    fprintf(stderr, "\n");
+  }
   // T = (M[p_R, :] * Q_S^H) * L_SS^-1, block columns from the right
   std::vector<T*> YR(nj, nullptr), T2(nj, nullptr);
   for (int a = 0; a < nj; ++a) {
@@ -1120,6 +1164,13 @@ bool compress_fixed(HssT<T>& H, std::vector<CBlock<T>>& cb, int k, BlockOp<T>* b
     }
     run_gemms(tmp, gemms, 0, s);
   }
+  // round-off level of every matrix's samples: HS_NOISE_REL * its largest row norm, before and after the low-rank update is taken off
+  unsigned long long* dynorm = reinterpret_cast<unsigned long long*>(tmp.getz<double>((size_t)F, s));
+  auto sample_scale = [&](const T* Yx, int cols) {
+    for (int b = 0; b < F; ++b)
+      hipLaunchKernelGGL(rownorm_max_kernel<T>, dim3((unsigned)((cb[b].n + 255) / 256)), dim3(256), 0, s, Yx + cb[b].off, ldn, cb[b].n, cols, dynorm + b);
+  };
+  sample_scale(Ys, k);
   {  // Ys -= C*(M*(Z*OPs)),  W -= ((PsT*C)*M)*Z for the matrices that carry a low-rank update
     std::vector<GemmProb<T>> ga, gb, gc;
     for (auto& B : cb) {
@@ -1150,6 +1201,15 @@ bool compress_fixed(HssT<T>& H, std::vector<CBlock<T>>& cb, int k, BlockOp<T>* b
     run_rows(tmp, rows, s);
   }
 
+  sample_scale(Y, k2);
+  std::vector<double> noise(F, 0.0);
+  HSS_HIP(hipMemcpyAsync(noise.data(), dynorm, sizeof(double) * (size_t)F, hipMemcpyDeviceToHost, s));
+  HSS_HIP(hipStreamSynchronize(s));
+  double noise_max = 0.0;
+  for (double& x : noise) {
+    x *= noise_rel();
+    noise_max = std::max(noise_max, x);
+  }
   vlap(bop ? "samples Op*Omega, Op^T*Psi (matrix-free)" : "samples A*Omega, Psi^T*A", 0);
   const int N = (int)nd.size();
   // local sample / test blocks of every node (leaf: rows lo:hi of Y / OP), global index of every local position
@@ -1229,7 +1289,7 @@ bool compress_fixed(HssT<T>& H, std::vector<CBlock<T>>& cb, int k, BlockOp<T>* b
     // that couples weakly (or not at all) is noise of the children's truncation, and relative to ITSELF noise has full rank
     double gscale = 0.0;  // (the tolerance only matters to the LU-based rank rule, HS_HSS_QR=0: the largest scale of the batch)
     for (auto& B : cb) gscale = std::max(gscale, B.gscale);
-    const int st = lowrank_compress_batch<T>(jobs.data(), nj, std::max(H.opt.atol, H.opt.rtol * gscale) * lsc, H.opt.rtol * lsc, s, false);
+    const int st = lowrank_compress_batch<T>(jobs.data(), nj, std::max(std::max(H.opt.atol, H.opt.rtol * gscale) * lsc, noise_max), H.opt.rtol * lsc, s, false);
     for (int a = 0; a < nj; ++a) cb[nblk[L[a]]].gscale = std::max(cb[nblk[L[a]]].gscale, lr[a].top);
     vlap("pivot order (tournament LU of sketches)", lv);
     auto free_lr = [&]() {
@@ -1253,6 +1313,7 @@ bool compress_fixed(HssT<T>& H, std::vector<CBlock<T>>& cb, int k, BlockOp<T>* b
         qj[a].p = lr[a].rperm;
         qj[a].rmax = lr[a].k;  // the pivoted LU ordered the first k (sketch width) rows; the orthogonalisation stops by itself once a block of 32 rows is below the threshold
         qj[a].atol_scale = std::max(H.opt.atol, H.opt.rtol * cb[nblk[i]].gscale_q);  // absolute threshold of ITS matrix (times lsc below)
+        qj[a].floor_abs = noise[nblk[i]];
       }
       try {
         qr_refine<T>(tmp, H.keep, qj, lsc, H.opt.rtol * lsc, 0.0, s);

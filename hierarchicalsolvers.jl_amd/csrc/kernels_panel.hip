@@ -866,11 +866,10 @@ __global__ __launch_bounds__(256) void trsm_small_kernel(const NodeDesc<T>* __re
 template <class T>
 bool launch_trsm_small(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int rows, int c0, int c1, int maxcols, hipStream_t s) {
   static const bool on = !(getenv("HS_TRSM_SMALL") && getenv("HS_TRSM_SMALL")[0] == '0');
-  // ComplexF64: off unless HS_TRSM_SMALL_Z=1.  Every parity test passes with it (the fronts' L, U to 1e-13).  It was switched off when the
-  // matrix-free block flow at tol 1e-12 (Helmholtz 24^3) ended at 8.5e-8 instead of 1.3e-11 -- which turned out to be the flow, not this kernel:
-  // below 1e-10 its error is erratic with EITHER path (tools/mf_exactness_probe.py: 3e-2 / 1e-11 / 1e-6 at 1e-11 / 1e-12 / 1e-13 with the
-  // recursion, 7e-3 / 9e-8 / 2e-5 with this kernel; at 1e-10 both give 1e-10).  Left off for ComplexF64 until that regime is understood.
-  static const bool on_z = getenv("HS_TRSM_SMALL_Z") && getenv("HS_TRSM_SMALL_Z")[0] == '1';
+  // ComplexF64: on since round 3 (HS_TRSM_SMALL_Z=0 turns it off).  Round 2 had switched it off when the matrix-free block flow at tol 1e-12
+  // ended at 8.5e-8 instead of 1.3e-11: that was the rank-revealing orthogonalisation accepting round-off as rank (hs_hss.hip, HS_CHOL_COND /
+  // HS_NOISE_REL; tests/test_mf_gpu.py::test_error_follows_the_tolerance_down_to_roundoff), which any round-off-level change of a kernel perturbed.
+  static const bool on_z = !(getenv("HS_TRSM_SMALL_Z") && getenv("HS_TRSM_SMALL_Z")[0] == '0');
   if (!on || (sizeof(T) == 16 && !on_z) || nbatch <= 0 || maxcols <= 0) return false;
   const dim3 grid((maxcols + HS_PB - 1) / HS_PB, nbatch);
   if (rows == 2 * HS_PB) {
