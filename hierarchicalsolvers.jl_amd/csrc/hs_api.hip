@@ -89,6 +89,7 @@ static void chkopts(const hs_options& o) {  // HierarchicalSolvers.jl:73-79
   if (!(o.rtol >= 0.0)) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: rtol");
   if (!(o.c_tol > 0.0 && o.c_tol <= 1.0)) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: c_tol");
   if (!(o.leafsize >= 1)) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: leafsize");
+  if (o.mf > 3) HS_FAIL(HS_ERR_ARGUMENT, o.mf, "ArgumentError: hs_options.mf must be in 0:3, got %d", (int)o.mf);
 }
 
 static void require_device() {
@@ -178,6 +179,7 @@ struct LevelH {
 struct Exchange {
   int node, level, src, dst, nb;
   long long nelems;
+  int hss = 0;  // 1: the node's Schur complement crosses as a packed HSS matrix (hs_schur_pack / hs_schur_unpack), not as a dense block
 };
 
 #include "hs_sched.h"
@@ -592,6 +594,17 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
       N[i].compressed = split.active ? (split.cflag[i] != 0) : hs_compression_flag(N[i].level, N[i].ni, N[i].nb, N[i].leaf, swlevel, opts.swsize);
     for (int i = 0; i < h->nreal; ++i)
       if (N[i].dist) N[i].compressed = false;  // fronts eliminated by a group of ranks are eliminated exactly (hs_dist.h)
+    // options this plan cannot honour are refused, never dropped (round 2 fell back to the dense-S flow with HS_OK)
+    if (opts.mf && split.active) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_options.mf together with hs_options.split: sliced fronts are eliminated on dense blocks");
+    if (opts.mf && nranks > 1 && opts.dist_top)
+      HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_options.mf together with hs_options.dist_top: group fronts are eliminated exactly; use dist_top = 0 (the joins then ship HSS generators)");
+    if (opts.hss_d > 0 && nranks > 1) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_options.hss_d with %d ranks: single-rank factorizations only (hs_options.mf runs over ranks)", nranks);
+    if (opts.hss_d > 0 && split.active) HS_FAIL(HS_ERR_UNSUPPORTED, 0, "hs_options.hss_d together with hs_options.split");
+    if (opts.dist_top && nranks > 1)
+      for (int i = 0; i < h->nreal; ++i)
+        if (N[i].dist && (split.active ? (split.cflag[i] != 0) : hs_compression_flag(N[i].level, N[i].ni, N[i].nb, N[i].leaf, swlevel, opts.swsize)))
+          HS_FAIL(HS_ERR_UNSUPPORTED, i, "hs_options.dist_top: node %d (level %d) is above the rank cut AND flagged for compression (swlevel = %lld); group fronts are eliminated "
+                                         "exactly -- use swlevel = 0 or dist_top = 0", i, N[i].level, (long long)opts.swlevel);
     if (opts.hss_d > 0 && nranks == 1 && !split.active && swlevel > 0 && !plan_only) {
       // fronts of the compressed levels with a large interior block keep D as an HSS matrix (hs_hssfront.h); the root too
       std::vector<int> where((size_t)n, -1);
@@ -605,14 +618,19 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
                          : hss_bisect_perm(h->fidx_host.data() + x.off_fidx, x.ni, n, colptr, rowval, where);
       }
     }
-    if (opts.mf && nranks == 1 && !split.active && swlevel > 0 && !plan_only) {
+    if (opts.mf && swlevel > 0) {
       // matrix-free compressed branch (hs_mffront.h): flagged fronts hand their Schur complement on as an HSS matrix, a parent of two
-      // such fronts is assembled from their generators and the sparse couplings of A
+      // such fronts is assembled from their generators and the sparse couplings of A.  The flags are properties of the TREE: with several
+      // ranks (dist_top = 0) a flagged child of another rank's front sends its HSS matrix packed into one buffer (hs_schur_pack / _unpack)
       mf_plan(h, swlevel);
-      std::vector<int> where((size_t)n, -1);
+      std::vector<int> where(plan_only ? (size_t)0 : (size_t)n, -1);
       for (int i = 0; i < h->nreal; ++i) {
         NodeH& x = N[i];
+        if (x.s_hss && (x.mine || x.ghost)) h->mf_on = true;
         if (!x.mf) continue;
+        x.mfd = opts.mf == 1 && !x.hssd;
+        x.mfb = opts.mf == 3;
+        if (!x.mine || plan_only) continue;
         h->mf_on = true;
         x.mfd = opts.mf == 1 && !x.hssd;  // mf == 2: D of every matrix-free front is ONE HSS matrix; mf == 3: the reference's 2x2 block form
         x.mfb = opts.mf == 3;
@@ -669,7 +687,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         x.lds = rup(std::max(x.nb, 1), 2);
         if (x.mine || x.ghost) {
           x.off_SB = sb;
-          if (!(x.mf && x.s_hss)) sb += rups((size_t)x.lds * x.nb, 32);  // a matrix-free front whose S leaves as HSS never holds it densely
+          // a matrix-free front whose S leaves as HSS never holds it densely; neither does a front of another rank whose S ARRIVES as HSS
+          if (!(x.mf && x.s_hss) && !(x.ghost && !x.mine && x.s_hss)) sb += rups((size_t)x.lds * x.nb, 32);
           x.off_cmap = ints;
           ints += x.nb;
         }
@@ -739,7 +758,10 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     for (int lv = 0; lv < (int)h->levels.size(); ++lv)
       for (int id : h->levels[lv].nodes)
         if (N[id].mine || N[id].ghost) N[id].off_SB += h->levels[lv].sb_begin;
-    for (auto& ex : h->exchanges) ex.nelems = (long long)N[ex.node].lds * N[ex.node].nb;
+    for (auto& ex : h->exchanges) {
+      ex.hss = N[ex.node].s_hss ? 1 : 0;  // the Schur complement of this node crosses ranks as a packed HSS matrix (size known after its compression)
+      ex.nelems = ex.hss ? 0 : (long long)N[ex.node].lds * N[ex.node].nb;
+    }
     h->fac_elems = fac;
     h->inv_elems = inv;
     h->sb_elems = sb_total;
@@ -1470,6 +1492,57 @@ extern "C" int hs_exchange_info(const hs_handle* h, int64_t k, int64_t* out6) {
            if (k < 0 || k >= (int64_t)h->exchanges.size() || !out6) HS_FAIL(HS_ERR_ARGUMENT, k, "BoundsError: exchange %lld", (long long)k);
            const Exchange& e = h->exchanges[k]; out6[0] = e.node; out6[1] = e.level; out6[2] = e.src; out6[3] = e.dst; out6[4] = e.nb;
            out6[5] = e.nelems);
+}
+extern "C" int64_t hs_exchange_kind(const hs_handle* h, int64_t k) {
+  if (!h || k < 0 || k >= (int64_t)h->exchanges.size()) return -1;
+  return h->exchanges[(size_t)k].hss;
+}
+// ---- a Schur complement that crosses ranks as an HSS matrix (hs_options.mf with nranks > 1, dist_top = 0) ---------------------------------
+static NodeH& schur_hss_node(hs_handle* h, int64_t node, bool need_matrix) {
+  check_device_handle(h);
+  if (node < 0 || node >= h->nnodes) HS_FAIL(HS_ERR_ARGUMENT, node, "BoundsError: node %lld", (long long)node);
+  NodeH& x = h->nodes[(size_t)node];
+  if (!x.s_hss) HS_FAIL(HS_ERR_ARGUMENT, node, "ArgumentError: the Schur complement of node %lld does not travel as an HSS matrix (hs_exchange_kind)", (long long)node);
+  if (need_matrix && !x.S_hss)
+    HS_FAIL(HS_ERR_ARGUMENT, node, "ArgumentError: node %lld holds no HSS Schur complement yet (factor its level first; a parent on this rank may have absorbed it)", (long long)node);
+  return x;
+}
+extern "C" int hs_schur_pack_size(hs_handle* h, int64_t node, int64_t* bytes) {
+  HS_GUARD(if (!bytes) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: bytes == NULL"); NodeH& x = schur_hss_node(h, node, true);
+           HS_HIP(hipStreamSynchronize(h->stream));  // the compression that produced it ran on the handle's (or a worker's, already joined) stream
+           const int st = hs_hss_pack_size((hs_hss*)x.S_hss, bytes); if (st != 0) throw HsError{st});
+}
+extern "C" int hs_schur_pack(hs_handle* h, int64_t node, void* dev_buf, int64_t bytes, void* stream) {
+  HS_GUARD(NodeH& x = schur_hss_node(h, node, true);
+           const int st = hs_hss_pack((hs_hss*)x.S_hss, dev_buf, bytes, stream ? stream : (void*)h->stream); if (st != 0) throw HsError{st};
+           if (!h->opts.keep_schur && !(x.parent >= 0 && h->nodes[(size_t)x.parent].mine)) {  // sent away: nothing on this rank reads it again
+             hs_hss_free((hs_hss*)x.S_hss);
+             x.S_hss = nullptr;
+           });
+}
+extern "C" int hs_schur_unpack(hs_handle* h, int64_t node, const void* dev_buf, int64_t bytes, void* stream) {
+  HS_GUARD(NodeH& x = schur_hss_node(h, node, false);
+           if (!x.ghost && !x.mine) HS_FAIL(HS_ERR_ARGUMENT, node, "ArgumentError: node %lld is neither owned nor received by rank %d", (long long)node, h->rank);
+           if (x.S_hss) { hs_hss_free((hs_hss*)x.S_hss); x.S_hss = nullptr; }
+           hs_hss* H = nullptr;
+           const int st = hs_hss_unpack(dev_buf, bytes, h->is_complex ? 1 : 0, stream ? stream : (void*)h->stream, &H); if (st != 0) throw HsError{st};
+           if (hs_hss_size(H) != x.nb) { hs_hss_free(H); HS_FAIL(HS_ERR_DIMENSION, node, "DimensionMismatch: received an HSS matrix of order %lld for node %lld with |bnd| = %d",
+                                                                  (long long)hs_hss_size(H), (long long)node, x.nb); }
+           x.S_hss = H;
+           { std::lock_guard<std::mutex> lk(g_mf_mu); h->maxrank = std::max<int64_t>(h->maxrank, hs_hss_rank(H)); });
+}
+// out8 = {hs_options.mf in effect (0: the dense-S flow), matrix-free fronts of this rank, fronts of this rank whose S leaves as HSS, fronts with low-rank L / R,
+//         fronts whose D is an HSS matrix (hss_d), group fronts (dist_top), ranks, fronts eliminated in slices}: what a run actually did with its options
+extern "C" int hs_flow_info(const hs_handle* h, int64_t* out8) {
+  HS_GUARD(check_handle(h); if (!out8) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: out8 == NULL");
+           for (int k = 0; k < 8; ++k) out8[k] = 0;
+           out8[0] = h->mf_on ? h->opts.mf : 0; out8[6] = h->nranks;
+           for (int i = 0; i < h->nreal; ++i) {
+             const NodeH& x = h->nodes[(size_t)i];
+             if (!x.mine) continue;
+             out8[1] += x.mf ? 1 : 0; out8[2] += x.s_hss ? 1 : 0; out8[3] += (x.compressed && !x.leaf) ? 1 : 0; out8[4] += x.hssd ? 1 : 0; out8[5] += x.dist ? 1 : 0;
+             out8[7] += x.kind != 0 ? 1 : 0;
+           });
 }
 extern "C" int64_t hs_node_owner(const hs_handle* h, int64_t node) {
   if (!h || node < 0 || node >= h->nnodes) return -1;

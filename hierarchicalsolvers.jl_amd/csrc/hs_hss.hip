@@ -2682,6 +2682,202 @@ extern "C" int hs_hss_compatible(const hs_hss* A, const hs_hss* B) {
 }
 extern "C" int64_t hs_hss_depth(const hs_hss* H) { return H ? HSS_DISPATCH(H, HD(H)->nlev, HZ(H)->nlev) : 0; }
 
+// ------------------------------------------------------------------------------------------------
+// One contiguous device buffer for a whole HSS matrix -- what crosses ranks at a join of the elimination tree when the child's Schur
+// complement travels as an HssMatrix (src/factorization.jl:78-112: the parent reads S1, S2 as HSS; SURVEY.md 8(e): "ship HSS generators
+// instead of dense S"): 100 MB of generators instead of a 2.1 GB dense block at the top of Poisson 128^3.  Layout: PackHdr, nnodes x
+// PackNode, the permutation (n ints, if any), then every generator block at a 256-byte aligned offset with the leading dimension it
+// has here.  Factors of an elimination (hs_hss_factor) and the lazily made transposes are not packed: the receiver rebuilds them on
+// first use.  Unpacking copies the buffer ONCE into a block the new matrix owns and points its nodes into it.
+// ------------------------------------------------------------------------------------------------
+struct PackHdr {
+  int64_t magic, bytes, is_complex, n, k, nlev, nnodes, has_perm, off_nodes, off_perm;
+  hs_hss_options opt;
+  int64_t reserved[4];
+};
+struct PackNode {
+  int32_t lo, hi, left, right, parent, level, m, r, ldt, ldtt, ldd, ld12, ld21, off_in_parent, rl, rr;
+  int64_t o_p, o_sk, o_Tm, o_Tt, o_D, o_B12, o_B21;  // byte offsets from the start of the buffer, -1: absent
+};
+static constexpr int64_t HS_PACK_MAGIC = 0x4853534850414b31ll;  // "HSSHPAK1"
+static inline int64_t pack_up(int64_t b) { return (b + 255) / 256 * 256; }
+
+template <class T>
+static void pack_layout(const HssT<T>* H, PackHdr& hd, std::vector<PackNode>& pn) {
+  const int N = (int)H->nd.size();
+  memset(&hd, 0, sizeof hd);
+  hd.magic = HS_PACK_MAGIC;
+  hd.is_complex = sizeof(T) == 16;
+  hd.n = H->n; hd.k = H->k; hd.nlev = H->nlev; hd.nnodes = N;
+  hd.has_perm = H->perm != nullptr;
+  hd.opt = H->opt;
+  pn.assign((size_t)N, PackNode());
+  int64_t at = pack_up((int64_t)sizeof(PackHdr));
+  hd.off_nodes = at;
+  at = pack_up(at + (int64_t)sizeof(PackNode) * N);
+  hd.off_perm = -1;
+  if (H->perm) {
+    hd.off_perm = at;
+    at = pack_up(at + (int64_t)sizeof(int) * H->n);
+  }
+  auto blob = [&](const void* ptr, int64_t bytes) -> int64_t {
+    if (!ptr || bytes <= 0) return -1;
+    const int64_t o = at;
+    at = pack_up(at + bytes);
+    return o;
+  };
+  for (int i = 0; i < N; ++i) {
+    const HNode<T>& x = H->nd[i];
+    PackNode& q = pn[(size_t)i];
+    q.lo = x.lo; q.hi = x.hi; q.left = x.left; q.right = x.right; q.parent = x.parent; q.level = x.level; q.m = x.m; q.r = x.r;
+    q.ldt = x.ldt; q.ldtt = x.ldtt; q.ldd = x.ldd; q.ld12 = x.ld12; q.ld21 = x.ld21; q.off_in_parent = x.off_in_parent;
+    q.rl = x.left >= 0 ? H->nd[x.left].r : 0;
+    q.rr = x.right >= 0 ? H->nd[x.right].r : 0;
+    const int nR = x.m - x.r;
+    q.o_p = blob(x.p, (int64_t)sizeof(int) * x.m);
+    q.o_sk = blob(x.sk, (int64_t)sizeof(int) * x.r);
+    q.o_Tm = blob(x.Tm, (int64_t)sizeof(T) * x.ldt * x.r);
+    q.o_Tt = blob(x.Tt, (int64_t)sizeof(T) * x.ldtt * std::max(nR, 0));
+    q.o_D = blob(x.left < 0 ? x.D : nullptr, (int64_t)sizeof(T) * x.ldd * x.m);
+    q.o_B12 = blob(x.B12, (int64_t)sizeof(T) * x.ld12 * q.rr);
+    q.o_B21 = blob(x.B21, (int64_t)sizeof(T) * x.ld21 * q.rl);
+  }
+  hd.bytes = at;
+}
+
+template <class T>
+static int64_t pack_size_impl(const HssT<T>* H) {
+  PackHdr hd;
+  std::vector<PackNode> pn;
+  pack_layout(H, hd, pn);
+  return hd.bytes;
+}
+
+template <class T>
+static void pack_impl(HssT<T>* H, void* buf, int64_t bytes, hipStream_t s) {
+  PackHdr hd;
+  std::vector<PackNode> pn;
+  pack_layout(H, hd, pn);
+  if (!buf || bytes < hd.bytes) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_pack needs a device buffer of %lld bytes, got %lld", (long long)hd.bytes, (long long)bytes);
+    throw (int)HS_ERR_ARGUMENT;
+  }
+  if (!s) s = H->s;
+  char* base = (char*)buf;
+  Pool tmp(global_cache());
+  void* hp = tmp.get_pinned(sizeof(PackHdr) + sizeof(PackNode) * pn.size());
+  memcpy(hp, &hd, sizeof hd);
+  memcpy((char*)hp + sizeof hd, pn.data(), sizeof(PackNode) * pn.size());
+  HSS_HIP(hipMemcpyAsync(base, hp, sizeof hd, hipMemcpyHostToDevice, s));
+  HSS_HIP(hipMemcpyAsync(base + hd.off_nodes, (char*)hp + sizeof hd, sizeof(PackNode) * pn.size(), hipMemcpyHostToDevice, s));
+  if (H->perm) HSS_HIP(hipMemcpyAsync(base + hd.off_perm, H->perm, sizeof(int) * (size_t)H->n, hipMemcpyDeviceToDevice, s));
+  auto put = [&](int64_t off, const void* src, int64_t nbytes) {
+    if (off >= 0) HSS_HIP(hipMemcpyAsync(base + off, src, (size_t)nbytes, hipMemcpyDeviceToDevice, s));
+  };
+  for (size_t i = 0; i < pn.size(); ++i) {
+    const HNode<T>& x = H->nd[i];
+    const PackNode& q = pn[i];
+    put(q.o_p, x.p, (int64_t)sizeof(int) * x.m);
+    put(q.o_sk, x.sk, (int64_t)sizeof(int) * x.r);
+    put(q.o_Tm, x.Tm, (int64_t)sizeof(T) * x.ldt * x.r);
+    put(q.o_Tt, x.Tt, (int64_t)sizeof(T) * x.ldtt * std::max(x.m - x.r, 0));
+    put(q.o_D, x.D, (int64_t)sizeof(T) * x.ldd * x.m);
+    put(q.o_B12, x.B12, (int64_t)sizeof(T) * x.ld12 * q.rr);
+    put(q.o_B21, x.B21, (int64_t)sizeof(T) * x.ld21 * q.rl);
+  }
+  HSS_HIP(hipStreamSynchronize(s));  // the pinned staging block goes back to its cache with `tmp`
+}
+
+template <class T>
+static HssT<T>* unpack_impl(const void* buf, int64_t bytes, hipStream_t s) {
+  PackHdr hd;
+  if (!buf || bytes < (int64_t)sizeof hd) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_unpack: buffer of %lld bytes holds no header", (long long)bytes);
+    throw (int)HS_ERR_ARGUMENT;
+  }
+  HSS_HIP(hipMemcpyAsync(&hd, buf, sizeof hd, hipMemcpyDeviceToHost, s));
+  HSS_HIP(hipStreamSynchronize(s));
+  if (hd.magic != HS_PACK_MAGIC || hd.bytes > bytes || hd.is_complex != (int64_t)(sizeof(T) == 16) || hd.nnodes <= 0 || hd.n <= 0 ||
+      hd.off_nodes + (int64_t)sizeof(PackNode) * hd.nnodes > hd.bytes) {
+    hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_unpack: not a packed %s HSS matrix of at most %lld bytes", sizeof(T) == 16 ? "ComplexF64" : "Float64", (long long)bytes);
+    throw (int)HS_ERR_ARGUMENT;
+  }
+  std::vector<PackNode> pn((size_t)hd.nnodes);
+  HSS_HIP(hipMemcpyAsync(pn.data(), (const char*)buf + hd.off_nodes, sizeof(PackNode) * pn.size(), hipMemcpyDeviceToHost, s));
+  std::unique_ptr<HssT<T>> H(new HssT<T>());
+  H->n = (int)hd.n; H->k = (int)hd.k; H->nlev = (int)hd.nlev;
+  H->opt = hd.opt;
+  H->s = s;
+  H->own_stream = false;
+  if (!s) {
+    HSS_HIP(hipStreamCreate(&H->s));
+    H->own_stream = true;
+    s = H->s;
+  }
+  char* base = H->keep.template get<char>((size_t)hd.bytes);
+  HSS_HIP(hipMemcpyAsync(base, buf, (size_t)hd.bytes, hipMemcpyDeviceToDevice, s));
+  if (hd.has_perm) {
+    H->perm = (int*)(base + hd.off_perm);
+    H->hperm.assign((size_t)hd.n, 0);
+    HSS_HIP(hipMemcpyAsync(H->hperm.data(), (const char*)buf + hd.off_perm, sizeof(int) * (size_t)hd.n, hipMemcpyDeviceToHost, s));
+  }
+  HSS_HIP(hipStreamSynchronize(s));
+  if (hd.has_perm) {
+    H->hinvperm.assign((size_t)hd.n, 0);
+    for (int64_t i = 0; i < hd.n; ++i) {
+      const int v = H->hperm[(size_t)i];
+      if (v < 0 || v >= hd.n) {
+        hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_unpack: corrupt permutation");
+        throw (int)HS_ERR_ARGUMENT;
+      }
+      H->hinvperm[(size_t)v] = (int)i;
+    }
+  }
+  auto at = [&](int64_t off, int64_t nbytes) -> char* {
+    if (off < 0) return nullptr;
+    if (off + nbytes > hd.bytes) {
+      hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_unpack: a generator block lies outside the buffer");
+      throw (int)HS_ERR_ARGUMENT;
+    }
+    return base + off;
+  };
+  H->nd.assign((size_t)hd.nnodes, HNode<T>());
+  for (size_t i = 0; i < pn.size(); ++i) {
+    const PackNode& q = pn[i];
+    HNode<T>& x = H->nd[i];
+    if (q.left >= hd.nnodes || q.right >= hd.nnodes || q.parent >= hd.nnodes || q.level < 0 || q.level >= hd.nlev || q.m < 0 || q.r < 0 || q.r > q.m) {
+      hs_set_error(HS_ERR_ARGUMENT, 0, "ArgumentError: hs_hss_unpack: corrupt node table");
+      throw (int)HS_ERR_ARGUMENT;
+    }
+    x.lo = q.lo; x.hi = q.hi; x.left = q.left; x.right = q.right; x.parent = q.parent; x.level = q.level; x.m = q.m; x.r = q.r;
+    x.ldt = q.ldt; x.ldtt = q.ldtt; x.ldd = q.ldd; x.ld12 = q.ld12; x.ld21 = q.ld21; x.off_in_parent = q.off_in_parent;
+    x.p = (int*)at(q.o_p, (int64_t)sizeof(int) * q.m);
+    x.sk = (int*)at(q.o_sk, (int64_t)sizeof(int) * q.r);
+    x.Tm = (T*)at(q.o_Tm, (int64_t)sizeof(T) * q.ldt * q.r);
+    x.Tt = (T*)at(q.o_Tt, (int64_t)sizeof(T) * q.ldtt * std::max(q.m - q.r, 0));
+    x.D = (T*)at(q.o_D, (int64_t)sizeof(T) * q.ldd * q.m);
+    x.B12 = (T*)at(q.o_B12, (int64_t)sizeof(T) * q.ld12 * q.rr);
+    x.B21 = (T*)at(q.o_B21, (int64_t)sizeof(T) * q.ld21 * q.rl);
+  }
+  H->lev.assign((size_t)H->nlev, {});
+  for (int i = 0; i < (int)H->nd.size(); ++i) H->lev[(size_t)H->nd[(size_t)i].level].push_back(i);
+  return H.release();
+}
+
+extern "C" int hs_hss_pack_size(const hs_hss* H, int64_t* bytes) {
+  if (!H || !bytes) return HS_ERR_ARGUMENT;
+  HSS_GUARD(*bytes = HSS_DISPATCH(H, pack_size_impl(HD(H)), pack_size_impl(HZ(H))));
+}
+extern "C" int hs_hss_pack(hs_hss* H, void* dev_buf, int64_t bytes, void* stream) {
+  if (!H) return HS_ERR_ARGUMENT;
+  HSS_GUARD(if (H->is_complex) pack_impl(HZ(H), dev_buf, bytes, (hipStream_t)stream); else pack_impl(HD(H), dev_buf, bytes, (hipStream_t)stream));
+}
+extern "C" int hs_hss_unpack(const void* dev_buf, int64_t bytes, int is_complex, void* stream, hs_hss** out) {
+  if (!out) return HS_ERR_ARGUMENT;
+  *out = nullptr;
+  HSS_GUARD(*out = is_complex ? new hs_hss{1, unpack_impl<cplx>(dev_buf, bytes, (hipStream_t)stream)} : new hs_hss{0, unpack_impl<double>(dev_buf, bytes, (hipStream_t)stream)});
+}
+
 extern "C" int hs_hss_child(hs_hss* H, int which, hs_hss** out) {
   if (!H || !out || which < 0 || which > 2) return HS_ERR_ARGUMENT;
   *out = nullptr;

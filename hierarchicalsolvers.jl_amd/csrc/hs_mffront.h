@@ -42,7 +42,7 @@ static void mf_plan(hs_handle* h, int64_t swlevel) {
   std::vector<NodeH>& N = h->nodes;
   const int leaf = mf_hss_leaf(h->opts);
   auto wants = [&](const NodeH& x) {  // compression_flag of factorization.jl:15 (a flagged LEAF compresses its S too, :45-59)
-    return x.level >= 2 && x.level <= swlevel && x.nb >= h->opts.swsize && x.nb > leaf && x.ni > 0 && x.mine && x.parent >= 0 && N[x.parent].level >= 1;
+    return x.level >= 2 && x.level <= swlevel && x.nb >= h->opts.swsize && x.nb > leaf && x.ni > 0 && x.parent >= 0 && N[x.parent].level >= 1;
   };
   for (int i = 0; i < h->nreal; ++i) {
     NodeH& x = N[i];
@@ -58,7 +58,7 @@ static void mf_plan(hs_handle* h, int64_t swlevel) {
 static void mf_sperm(hs_handle* h, const std::vector<int>& hint) {
   for (int i = 0; i < h->nreal; ++i) {
     NodeH& x = h->nodes[i];
-    if (!x.s_hss) continue;
+    if (!x.s_hss || !(x.mine || x.ghost)) continue;
     const int* cm = hint.data() + x.off_cmap;
     const NodeH& p = h->nodes[x.parent];
     x.sperm.resize((size_t)x.nb);
@@ -74,7 +74,7 @@ static void mf_couplings(hs_handle* h, int64_t n, const int64_t* colptr, const i
   std::vector<int> where((size_t)n, -1);
   for (int i = 0; i < h->nreal; ++i) {
     NodeH& x = h->nodes[i];
-    if (!x.mf) continue;
+    if (!x.mf || !x.mine) continue;
     const int* F = h->fidx_host.data() + x.off_fidx;
     for (int p = 0; p < x.m; ++p) where[F[p]] = p;
     auto part = [&](int p) { return p < x.ni ? (p < x.ni1 ? 1 : 2) : ((p - x.ni) < x.nb1 ? 1 : 2); };

@@ -230,6 +230,25 @@ def run_numeric(backend, plan, rank, comm):
     backend.numeric_levels(L, cut)
     for lv in range(cut - 1, 0, -1):
         for e in plan.at_child_level(lv + 1):
+            if e.get("hss"):
+                # the matrix-free flow over ranks (hs_options.mf): the child's Schur complement is an HssMatrix (src/factorization.jl:78-112,126-140);
+                # its generators cross packed into one buffer -- the byte count first, it is known only after the compression
+                if e["src"] == rank:
+                    buf = backend.schur_hss_pack(e["node"])
+                    comm.send(backend.size_tensor(buf.numel()), e["dst"])
+                    comm.send(buf, e["dst"])
+                    backend.comm_sync()
+                    backend.note_transfer(buf.numel())
+                elif e["dst"] == rank:
+                    nbytes = backend.size_tensor(0)
+                    comm.recv(nbytes, e["src"])
+                    backend.comm_sync()
+                    buf = backend.byte_buffer(int(nbytes.item()))
+                    comm.recv(buf, e["src"])
+                    backend.comm_sync()
+                    backend.schur_hss_unpack(e["node"], buf)
+                    backend.note_transfer(buf.numel())
+                continue
             if e["src"] == rank:
                 backend.sync()
                 comm.send(backend.schur_tensor(e["node"]), e["dst"])
@@ -341,7 +360,7 @@ class HipBackend:
         out6 = (C.c_int64 * 6)()
         for k in range(self.L.hs_num_exchanges(h)):
             _lib.check(self.L.hs_exchange_info(h, k, out6))
-            ex.append(dict(node=out6[0], level=out6[1], src=out6[2], dst=out6[3], nb=out6[4], nelems=out6[5]))
+            ex.append(dict(node=out6[0], level=out6[1], src=out6[2], dst=out6[3], nb=out6[4], nelems=out6[5], hss=int(self.L.hs_exchange_kind(h, k)) == 1))
         self.plan = Plan(self.L.hs_nlevels(h), self.L.hs_cut_level(h), ex, self.nranks)
         # exchange buffers live in torch memory and are registered with the library
         self._schur, self._bnd = {}, {}
@@ -353,7 +372,7 @@ class HipBackend:
             _lib.check(self.L.hs_set_comm(h, self.libcomm.handle))
         for e in ex:
             if self.rank in (e["src"], e["dst"]):
-                if not self.dist_top:
+                if not self.dist_top and not e["hss"]:
                     s = torch.zeros(max(int(e["nelems"]), 1), dtype=self.t_dtype, device=self.device)
                     _lib.check(self.L.hs_set_schur_buffer(h, e["node"], C.c_void_p(s.data_ptr())))
                     self._schur[e["node"]] = s
@@ -387,6 +406,32 @@ class HipBackend:
 
     def schur_tensor(self, node):
         return self._schur[node]
+
+    # -- Schur complements that cross ranks as HSS matrices (hs_options.mf) -----------------------------------------------------
+    def schur_hss_pack(self, node):
+        nb = C.c_int64(0)
+        _lib.check(self.L.hs_schur_pack_size(self._h, node, C.byref(nb)))
+        buf = self.torch.empty(int(nb.value), dtype=self.torch.uint8, device=self.device)
+        _lib.check(self.L.hs_schur_pack(self._h, node, C.c_void_p(buf.data_ptr()), int(nb.value), None))  # returns when the buffer is complete
+        return buf
+
+    def schur_hss_unpack(self, node, buf):
+        _lib.check(self.L.hs_schur_unpack(self._h, node, C.c_void_p(buf.data_ptr()), int(buf.numel()), None))
+
+    def size_tensor(self, value):
+        return self.torch.tensor([int(value)], dtype=self.torch.int64, device=self.device)
+
+    def byte_buffer(self, nbytes):
+        return self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+
+    def note_transfer(self, nbytes):
+        self.hss_bytes_moved = getattr(self, "hss_bytes_moved", 0) + int(nbytes)
+
+    def flow_info(self):
+        out = (C.c_int64 * 8)()
+        _lib.check(self.L.hs_flow_info(self._h, out))
+        keys = ("mf", "mf_fronts", "hss_schur_fronts", "lowrank_fronts", "hss_d_fronts", "group_fronts", "nranks", "sliced_fronts")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def sync(self):
         """Library stream -> host: data the library produced is complete before the communicator reads it."""

@@ -189,6 +189,24 @@ class HssMatrix:
         _lib.check(self.L.hs_hss_ldiv(self._h, B2.ctypes.data_as(C.c_void_p), n, q, 0))
         return B2[:, 0] if one else B2
 
+    def pack(self, device="cuda:0"):
+        """The whole matrix in ONE device buffer (a ``torch.uint8`` tensor): what crosses ranks at a join when a child's Schur complement
+        travels as an ``HssMatrix`` (src/factorization.jl:126-140 reads S1, S2 as HSS; include/hs_hss.h ``hs_hss_pack``)."""
+        import torch
+
+        nb = C.c_int64(0)
+        _lib.check(self.L.hs_hss_pack_size(self._h, C.byref(nb)))
+        buf = torch.empty(int(nb.value), dtype=torch.uint8, device=device)
+        _lib.check(self.L.hs_hss_pack(self._h, C.c_void_p(buf.data_ptr()), int(nb.value), None))
+        return buf
+
+    @staticmethod
+    def unpack(buf, is_complex):
+        """A new matrix from a packed buffer (``pack`` of another rank); the buffer is copied and may be dropped."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hs_hss_unpack(C.c_void_p(buf.data_ptr()), int(buf.numel()), int(bool(is_complex)), None, C.byref(h)))
+        return HssMatrix(h, bool(is_complex))
+
     def full(self):
         return self.matmul(np.eye(self.shape[0], dtype=self.dtype))
 

@@ -114,6 +114,15 @@ int hs_hss_mul_t(hs_hss* H, const double* X, int64_t ldx, double* Y, int64_t ldy
  * what `_assemble_blocks` reads from a child's Schur complement (src/factorization.jl:127-135).  Its index space is the block's own,
  * 0 .. size-1 in cluster-tree order.  HS_ERR_HSS_LEAF when H is a single leaf (factorization.jl:164). */
 int hs_hss_child(hs_hss* H, int which, hs_hss** out);
+/* One contiguous DEVICE buffer for a whole HSS matrix: what crosses ranks at a join of the elimination tree when a child's Schur complement
+ * travels as an HssMatrix (src/factorization.jl:78-112,126-140; SURVEY.md 8(e): "ship HSS generators instead of dense S").
+ *   hs_hss_pack_size : bytes the packed form takes
+ *   hs_hss_pack      : writes it to dev_buf (device pointer, at least that many bytes) on `stream` (NULL: the matrix's own); returns when done
+ *   hs_hss_unpack    : a new matrix from a packed buffer (device pointer; it is copied, the caller keeps dev_buf); is_complex must match
+ * Generators, permutation, cluster tree and options travel; the factors of hs_hss_factor do not (the receiver eliminates again if it needs to). */
+int hs_hss_pack_size(const hs_hss* H, int64_t* bytes);
+int hs_hss_pack(hs_hss* H, void* dev_buf, int64_t bytes, void* stream);
+int hs_hss_unpack(const void* dev_buf, int64_t bytes, int is_complex, void* stream, hs_hss** out);
 /* The off-diagonal blocks of the top-level split in low-rank form, A12 = C*Z (which = 0: C = U_1*B12 is n1 x r2, Z = U_2^T is r2 x n2) or
  * A21 = C*Z (which = 1: C = U_2*B21 is n2 x r1, Z = U_1^T is r1 x n1): the factors `Uint = generators(S.A11)[1]*S.B12`, `Vbnd` that a parent
  * front takes its low-rank couplings Aib, Abi from (src/factorization.jl:129-137).  Sizes and ranks: hs_hss_node_info of nodes 1 and 2. */

@@ -79,7 +79,8 @@ typedef struct hs_options {
                          1: D is expanded from the generators and eliminated densely by the front kernels (ni x ni, the one dense block of the
                             front), except on the fronts hss_d selects: the dense LU of a 32,768 block takes 0.5 s, its HSS compression +
                             elimination at 1e-4 1.8 s.
-                         Single rank only; hs_maxrank includes hssrank(S). */
+                         With nranks > 1 (dist_top = 0) the joins ship the children's HSS matrices packed into one buffer (hs_exchange_kind,
+                         hs_schur_pack / hs_schur_unpack); refused together with dist_top or split.  hs_maxrank includes hssrank(S). */
   uint8_t dist_top;   /* multi-rank factorizations (nranks > 1): 1 = every front ABOVE the rank cut is eliminated by all ranks of its group instead of
                          the group's first rank (the reference factors the two subtrees of a node one after the other although they are independent,
                          src/factorization.jl:20-21; above the cut the independent units are the block columns of one front): block columns of
@@ -168,6 +169,17 @@ int64_t hs_num_exchanges(const hs_handle* F);
  * node's Schur complement goes src -> dst before dst eliminates node's parent; in ldiv! the vector b[bnd(node)]
  * goes src -> dst in the forward sweep and dst -> src in the backward sweep. */
 int hs_exchange_info(const hs_handle* F, int64_t k, int64_t* out6);
+/* 0: exchange k moves a dense Schur complement (hs_set_schur_buffer); 1: it moves an HSS matrix packed into one buffer whose size is known
+ * only after the sender compressed it (hs_options.mf with nranks > 1: src calls hs_schur_pack_size + hs_schur_pack after the node's level,
+ * ships the byte count and the buffer, dst calls hs_schur_unpack before the parent's level).  This is the reference's data flow over ranks:
+ * the parent reads its children's S as HssMatrix objects (src/factorization.jl:78-112,126-140); out6[5] is 0 for such an exchange. */
+int64_t hs_exchange_kind(const hs_handle* F, int64_t k);
+int hs_schur_pack_size(hs_handle* F, int64_t node, int64_t* bytes);
+int hs_schur_pack(hs_handle* F, int64_t node, void* dev_buf, int64_t bytes, void* stream);   /* returns when the buffer is complete */
+int hs_schur_unpack(hs_handle* F, int64_t node, const void* dev_buf, int64_t bytes, void* stream);
+/* What a factorization does with its options on THIS rank: out8 = {hs_options.mf in effect (0 = the dense-S flow), matrix-free fronts, fronts whose S
+ * leaves as an HSS matrix, fronts with low-rank L / R, fronts with an HSS D (hss_d), group fronts (dist_top), ranks, fronts eliminated in slices}. */
+int hs_flow_info(const hs_handle* F, int64_t* out8);
 /* make `dptr` (device memory owned by the caller, hs_exchange_info's element count) the node's Schur buffer */
 int hs_set_schur_buffer(hs_handle* F, int64_t node, void* dptr);
 int hs_pack_bnd(const hs_handle* F, int64_t node, const void* d_b, void* d_buf, void* stream);   /* buf[j] = b[bnd_j] */

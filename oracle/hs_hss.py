@@ -392,3 +392,53 @@ def hss_offdiag(H):
     U1 = basis_rows(H, root.left, np.arange(l.lo, l.hi))
     U2 = basis_rows(H, root.right, np.arange(r.lo, r.hi))
     return U1, root.B12, U2, root.B21
+
+
+_PACK_FIELDS = ("p", "T", "sk", "D", "B12", "B21")
+
+
+def hss_pack(H):
+    """(int64 header, flat payload of H.dtype): the generators of an HSS matrix as two arrays -- what crosses ranks when a child's Schur
+    complement travels as an HssMatrix (the device counterpart is hs_hss_pack, include/hs_hss.h).  Index arrays ride in the
+    payload as real numbers (exact below 2^53)."""
+    ints, payload = [int(H.n), len(H.nodes), int(np.dtype(H.dtype) == np.complex128)], []
+    for x in H.nodes:
+        ints += [x.lo, x.hi, x.level, x.parent, x.left, x.right, x.m, x.r]
+        for f in _PACK_FIELDS:
+            a = getattr(x, f, None)
+            if a is None:
+                ints += [-1, 0, 0]
+                continue
+            a = np.asarray(a)
+            ints += [a.ndim, a.shape[0], a.shape[1] if a.ndim == 2 else 1]
+            payload.append(a.astype(H.dtype).ravel())
+    flat = np.concatenate(payload) if payload else np.zeros(0, dtype=H.dtype)
+    return np.asarray(ints, dtype=np.int64), np.ascontiguousarray(flat)
+
+
+def hss_unpack(ints, flat):
+    ints = [int(v) for v in ints]
+    n, nn, is_c = ints[:3]
+    dtype = np.complex128 if is_c else np.float64
+    flat = np.asarray(flat, dtype=dtype)
+    at, pos, nodes = 3, 0, []
+    for _ in range(nn):
+        lo, hi, level, parent, left, right, m, r = ints[at:at + 8]
+        at += 8
+        x = HssNode(lo, hi, level, parent)
+        x.left, x.right, x.m, x.r = left, right, m, r
+        for f in _PACK_FIELDS:
+            nd_, rows, cols = ints[at:at + 3]
+            at += 3
+            if nd_ < 0:
+                setattr(x, f, None)
+                continue
+            a = flat[pos:pos + rows * cols]
+            pos += rows * cols
+            a = a.reshape(rows, cols) if nd_ == 2 else a.reshape(rows)
+            if f in ("p", "sk"):
+                a = np.real(a).astype(np.int64)
+            setattr(x, f, a.copy())
+        nodes.append(x)
+    assert pos == len(flat) and at == len(ints)
+    return Hss(n, nodes, dtype)

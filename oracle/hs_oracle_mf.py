@@ -215,6 +215,23 @@ def factor(A, nd, nd_loc, dexp=2, dmode="block", opts=None, **kw):
 
 
 def _factor(A, nd, nd_loc, level, swlevel, opts, dsc):
+    """Post-order recursion (factorization.jl:14-27): children first, then `factor_node`."""
+    if O.isleaf(nd):
+        return factor_node(A, nd, nd_loc, level, swlevel, opts, dsc, None, None)
+    Fl = _factor(A, nd.left, nd_loc.left, level + 1, swlevel, opts, dsc)
+    Fr = _factor(A, nd.right, nd_loc.right, level + 1, swlevel, opts, dsc)
+    return factor_node(A, nd, nd_loc, level, swlevel, opts, dsc, Fl, Fr)
+
+
+def remote_child(S, nd_child, nd_loc_child):
+    """What a parent needs of a child it did not eliminate itself (a front of another rank, tests/test_dist_cpu.py): its Schur complement
+    `S` (HSS or dense, already in the order [int_loc; bnd_loc]), |int_loc| and the index sets."""
+    return Node(None, None, None, S, nd_child.int, nd_child.bnd, None, None, "remote", len(nd_loc_child.int))
+
+
+def factor_node(A, nd, nd_loc, level, swlevel, opts, dsc, Fl, Fr):
+    """Elimination of ONE front given its children's results (`_factor_leaf` / `_factor_branch`, factorization.jl:30-112): the unit a
+    level-by-level (and multi-rank) schedule calls."""
     flag = (level <= swlevel) and (len(nd.bnd) >= opts.swsize)
     n1 = len(nd_loc.int)
     perm = np.concatenate([nd_loc.int, nd_loc.bnd]) - 1
@@ -225,8 +242,6 @@ def _factor(A, nd, nd_loc, level, swlevel, opts, dsc):
             S = HS.compress(S, leafsize=opts.leafsize, atol=opts.atol, rtol=opts.rtol, kest=max(opts.kest, 16), first_split=n1 if n1 < len(nd.bnd) else None,
                             level_scale=0.5, fill=0.8)
         return Node(f.D, f.L, f.R, S, nd.int, nd.bnd, None, None, "dense", n1)
-    Fl = _factor(A, nd.left, nd_loc.left, level + 1, swlevel, opts, dsc)
-    Fr = _factor(A, nd.right, nd_loc.right, level + 1, swlevel, opts, dsc)
     int1 = nd.left.bnd[nd_loc.left.int - 1]
     bnd1 = nd.left.bnd[nd_loc.left.bnd - 1]
     int2 = nd.right.bnd[nd_loc.right.int - 1]

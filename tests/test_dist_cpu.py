@@ -462,3 +462,220 @@ def test_host_transfer_callback_over_gloo(world):
         p.join(timeout=60)
     for rank, ok in sorted(res):
         assert ok is True, (rank, ok)
+
+
+# ---- hs_options.mf over ranks: the joins ship HSS generators (src/factorization.jl:78-112,126-140) ---------------------------
+class OracleMfBackend(OracleBackend):
+    """The backend interface of dist.py on top of oracle/hs_oracle_mf.py, one front at a time (`factor_node`): a flagged front hands its
+    Schur complement on as an HSS matrix; where the parent lives on another rank the generators cross as ONE byte buffer (`hss_pack`), the
+    byte count first -- the same schedule (`run_numeric`, `run_solve`) the GPU path runs with hs_schur_pack / hs_schur_unpack."""
+
+    def __init__(self, A, ond, ond_loc, owner, level, rank, opts):
+        super().__init__(A, ond, ond_loc, owner, level, rank)
+        from oracle import hs_hss as HS
+        from oracle import hs_oracle_mf as OM
+
+        self.OM, self.HS, self.opts = OM, HS, opts
+        self.swlevel = opts.swlevel
+        self.dsc = 1e-2
+        self.keep = {}
+        self.moved = 0
+        OM._factor.G = None  # dmode = "block"
+
+    def numeric_levels(self, lv_from, lv_to):
+        for lv in range(lv_from, lv_to - 1, -1):
+            for k, x in enumerate(self.nodes):
+                if self.level[k] != lv or self.owner[k] != self.rank:
+                    continue
+                Fl = Fr = None
+                if x.left is not None:
+                    Fl, Fr = self.F[self.ids[id(x.left)]], self.F[self.ids[id(x.right)]]
+                self.F[k] = self.OM.factor_node(self.A, x, self.locs[k], lv, self.swlevel, self.opts, self.dsc, Fl, Fr)
+
+    def schur_hss_pack(self, node):
+        S = self.F[node].S
+        assert isinstance(S, self.HS.Hss), "the plan says HSS, the front produced a dense S"
+        ints, flat = self.HS.hss_pack(S)
+        head = np.array([len(ints), flat.nbytes], dtype=np.int64)
+        raw = np.concatenate([head.view(np.uint8), ints.view(np.uint8), flat.view(np.uint8)])
+        return self.torch.from_numpy(raw.copy())
+
+    def schur_hss_unpack(self, node, buf):
+        raw = buf.numpy()
+        nint, nbytes = (int(v) for v in raw[:16].view(np.int64))
+        ints = raw[16:16 + 8 * nint].view(np.int64)
+        is_c = bool(ints[2])
+        flat = raw[16 + 8 * nint:16 + 8 * nint + nbytes].view(np.complex128 if is_c else np.float64)
+        self.F[node] = self.OM.remote_child(self.HS.hss_unpack(ints, flat), self.nodes[node], self.locs[node])
+
+    def schur_tensor(self, node):  # a join whose child is NOT flagged ships the dense block, as on the exact path
+        nb = len(self.nodes[node].bnd)
+        if node not in self._schur:
+            self._schur[node] = self.torch.zeros(nb * nb, dtype=self.tdtype)
+        t = self._schur[node]
+        if self.owner[node] == self.rank:
+            t.copy_(self.torch.from_numpy(np.ascontiguousarray(self.F[node].S).reshape(-1)))
+        else:
+            self.F[node] = self.OM.remote_child(t.numpy().reshape(nb, nb), self.nodes[node], self.locs[node])
+        return t
+
+    def size_tensor(self, value):
+        return self.torch.tensor([int(value)], dtype=self.torch.int64)
+
+    def byte_buffer(self, nbytes):
+        return self.torch.empty(int(nbytes), dtype=self.torch.uint8)
+
+    def note_transfer(self, nbytes):
+        self.moved += int(nbytes)
+
+    def fwd(self, b, lv_from, lv_to):  # hs_oracle_mf._fwd, one front at a time
+        O = self.O
+        for lv in range(lv_from, max(lv_to, 1) - 1, -1):
+            for k in self._mine(lv, lv):
+                F = self.F[k]
+                i, bb = F.int - 1, F.bnd - 1
+                if F.kind == "mf":
+                    t = F.D.solve(b[i][:, None])[:, 0]
+                    self.keep[k] = t
+                    if len(bb):
+                        b[bb] = b[bb] - F.L.U @ (F.L.V.conj().T @ t)
+                elif len(bb):
+                    b[bb] = b[bb] - O._dense(F.L) @ b[i]
+
+    def bwd(self, b, lv_from, lv_to):
+        O = self.O
+        for lv in range(max(lv_from, 1), lv_to + 1):
+            for k in self._mine(lv, lv):
+                F = self.F[k]
+                i, bb = F.int - 1, F.bnd - 1
+                if F.kind == "mf":
+                    b[i] = self.keep[k] - (F.R.U @ (F.R.V.conj().T @ b[bb]) if len(bb) else 0)
+                else:
+                    d = O.blockldiv_inplace(F.D, b[i][:, None])[:, 0] if isinstance(F.D, O.BlockFactorization) else O._ldiv(F.D, b[i])
+                    b[i] = d - (O._dense(F.R) @ b[bb] if len(bb) else 0)
+
+
+def _worker_mf(rank, world, port, name, q):
+    try:
+        os.environ.setdefault("OMP_NUM_THREADS", "2")
+        os.environ.setdefault("OPENBLAS_NUM_THREADS", "2")
+        import torch  # noqa: F401
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hsamd
+
+        hs = hsamd.load()
+        from helpers import prepare
+        from hierarchicalsolvers_jl_amd.dist import TorchComm, run_numeric, run_solve
+        from oracle import hs_hss as HS
+        from oracle import hs_oracle as O
+        from oracle import hs_oracle_mf as OM
+
+        shape, kind, nmax, swlevel, leaf, tol = name
+        P = prepare(hs, shape, kind=kind, nmax=nmax, rhs="randn")
+        plan, owner, level = build_plan(hs, P["nd"], world)
+        opts = O.SolverOptions(swlevel=swlevel, swsize=8, atol=tol, rtol=tol, leafsize=leaf)
+        be = OracleMfBackend(P["A"], P["ond"], P["ond_loc"], owner, level, rank, opts)
+        # which joins ship generators: the child is flagged (factorization.jl:15) and its S is compressed (|int_loc| > 0, |bnd| > leafsize)
+        for e in plan.exchanges:
+            k = e["node"]
+            e["hss"] = level[k] <= swlevel and len(be.nodes[k].bnd) >= opts.swsize and len(be.locs[k].int) > 0 and len(be.nodes[k].bnd) > leaf
+        comm = TorchComm()
+        run_numeric(be, plan, rank, comm)
+        b = np.array(P["b"], dtype=be.dtype)
+        run_solve(be, plan, rank, comm, b)
+        Fs = OM.factor(P["A"], P["ond"], P["ond_loc"], opts=opts)  # the serial oracle: same fronts, same seeds, one process
+        xs = OM.ldiv(Fs, P["b"])
+        import scipy.sparse.linalg as spla
+
+        xe = spla.splu(P["A"]).solve(P["b"])
+        q.put((rank, float(np.linalg.norm(b - xs) / np.linalg.norm(xs)), float(np.linalg.norm(xs - xe) / np.linalg.norm(xe)),
+               sum(1 for e in plan.exchanges if e["hss"]), len(plan.exchanges), be.moved,
+               max((len(be.nodes[e["node"]].bnd) for e in plan.exchanges), default=0), OM.count_kinds(Fs), HS.__name__))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "ERR " + repr(e) + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,name", [(2, ((16, 16, 16), "poisson", 128, 3, 32, 1e-6)), (4, ((16, 16, 16), "poisson", 128, 3, 32, 1e-6)),
+                                        (2, ((12, 12, 10), "helmholtz", 64, 3, 24, 1e-5)), (2, ((32, 32, 32), "poisson", 512, 3, 128, 1e-4))])
+def test_matrix_free_flow_over_gloo(world, name):
+    """The reference's compressed data flow over ranks (src/factorization.jl:78-112,126-140): `run_numeric` / `run_solve` of dist.py -- the code
+    the GPU path runs -- with an oracle-backed backend.  Every join above the cut ships a packed HSS matrix (byte count first), never a dense
+    block, and the result is the SERIAL oracle's to round-off (same fronts, same seeds; the pack / unpack round trip is exact)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 3 + world * 41 + len(name[1])) % 2000
+    procs = [ctx.Process(target=_worker_mf, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in sorted(res):
+        assert not isinstance(r[1], str), r[1]
+        rank, err_serial, err_exact, nhss, nex, moved, nbmax, kinds = r[:8]
+        assert err_serial < 1e-11, (rank, err_serial)
+        assert err_exact < 100 * name[5]  # and the flow itself follows the tolerance
+        assert nhss == nex == world - 1
+        assert kinds.get("mf", 0) == 3
+    moved = [r[5] for r in res]
+    assert max(moved) > 0 and sum(moved) == 2 * sum(moved) // 2  # every byte that left one rank arrived at another
+    print("bytes of generators per rank:", moved)
+
+
+def test_mf_plan_over_ranks_and_refused_combinations(hs):
+    """hs_plan (host only): with hs_options.mf and nranks > 1 the flagged joins are HSS exchanges (round 2 dropped mf silently with nranks > 1);
+    combinations the library cannot honour are refused with HS_ERR_UNSUPPORTED / ArgumentError instead of falling back to another flow."""
+    import ctypes as C
+
+    from helpers import prepare
+
+    P = prepare(hs, (16, 16, 16), kind="poisson", nmax=128)
+    L = hs._lib.lib()
+    kw = dict(swlevel=3, swsize=8, atol=1e-4, rtol=1e-4, leafsize=64)
+    for world in (2, 4):
+        for rank in range(world):
+            h = hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=rank, nranks=world, mf="dense", **kw)
+            try:
+                n = L.hs_num_exchanges(h)
+                assert n == world - 1
+                out6 = (C.c_int64 * 6)()
+                for k in range(n):
+                    hs._lib.check(L.hs_exchange_info(h, k, out6))
+                    assert L.hs_exchange_kind(h, k) == 1 and out6[5] == 0  # generators, no dense element count
+                out8 = (C.c_int64 * 8)()
+                hs._lib.check(L.hs_flow_info(h, out8))
+                assert out8[6] == world
+            finally:
+                L.hs_free(h)
+        # without mf the same joins ship dense blocks
+        h = hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=world, **kw)
+        try:
+            assert all(L.hs_exchange_kind(h, k) == 0 for k in range(L.hs_num_exchanges(h)))
+        finally:
+            L.hs_free(h)
+    with pytest.raises(hs.UnsupportedError, match="dist_top"):
+        hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=2, mf="dense", dist_top=True, **kw)
+    with pytest.raises(hs.UnsupportedError, match="flagged for compression"):
+        hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=4, dist_top=True, **kw)  # level 2 is above the cut of 4 ranks and flagged
+    hs._lib.lib().hs_free(hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=2, dist_top=True, **kw))  # 2 ranks: only the root, never flagged
+    with pytest.raises(hs.UnsupportedError, match="hss_d"):
+        hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=2, hss_min=1024, **kw)
+    with pytest.raises(hs.UnsupportedError, match="split"):
+        hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=1, mf="dense", split_size=256, **kw)
+    # hs_options.mf outside 0:3 straight through the C ABI
+    opts = hs.SolverOptions(**kw).to_c()
+    opts.mf = 7
+    t, _keep = hs.dist._tree_struct(P["nd"], P["nd_loc"])
+    hh = C.c_void_p()
+    assert L.hs_plan(0, P["A"].shape[0], C.byref(t), C.byref(opts), 0, 1, C.byref(hh)) == hs._lib.HS_ERR_ARGUMENT
+    assert b"mf must be in 0:3" in L.hs_last_error()

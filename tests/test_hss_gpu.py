@@ -409,3 +409,50 @@ def test_trim_releases_the_recycled_blocks(hs):
     H2 = hs.hss.compress(K, leafsize=64, atol=1e-8, rtol=1e-8, kest=32)
     assert np.allclose(H2.ldiv(b), x0, rtol=1e-6, atol=1e-9)
     assert np.allclose(H.ldiv(b), x0)  # the generators a live matrix owns were never in the cache
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_pack_unpack_roundtrip(hs, complex_):
+    """`hs_hss_pack` / `hs_hss_unpack`: the one-buffer form in which a Schur complement crosses ranks as an HssMatrix ("ship
+    HSS generators instead of dense S"; src/factorization.jl:126-140 reads the children's S as HSS).  The unpacked matrix has the same tree and
+    the same generators bit for bit: products, entries, block views, off-diagonal factors, expansion and the solve are identical."""
+    rng = np.random.default_rng(5)
+    n = 900
+    A = kernel_matrix(n, complex_)
+    perm = np.arange(n)[::-1].copy()  # a permutation travels with the matrix (this one keeps the blocks compressible)
+    H = hs.hss.compress(A, leafsize=64, atol=1e-9, rtol=1e-9, kest=32, perm=perm)
+    buf = H.pack()
+    assert buf.dtype.itemsize == 1 and buf.numel() < 0.8 * A.nbytes  # generators, not the matrix
+    G = hs.hss.HssMatrix.unpack(buf, complex_)
+    del buf
+    assert G.shape == H.shape and G.rank == H.rank and G.num_nodes == H.num_nodes and G.samples == H.samples
+    for i in range(H.num_nodes):
+        a, b = H.node(i), G.node(i)
+        for k in ("lo", "hi", "level", "left", "right", "m", "r"):
+            assert a[k] == b[k], (i, k)
+        for k in ("p", "T", "D", "B12", "B21"):
+            if a[k] is None:
+                assert b[k] is None
+            else:
+                assert np.array_equal(a[k], b[k]), (i, k)
+    X = rng.standard_normal((n, 3)) + (1j * rng.standard_normal((n, 3)) if complex_ else 0)
+    assert np.array_equal(H.matmul(X), G.matmul(X))
+    assert np.array_equal(H.rmatmul_t(X), G.rmatmul_t(X))
+    I, J = rng.integers(0, n, 40), rng.integers(0, n, 50)
+    assert np.array_equal(H.getindex(I, J), G.getindex(I, J))
+    assert np.array_equal(H.full(), G.full())
+    for which in (0, 1):
+        assert np.array_equal(H.block(which).full(), G.block(which).full())
+        Ch, Zh = H.offdiag_lowrank(which)
+        Cg, Zg = G.offdiag_lowrank(which)
+        assert np.array_equal(Ch, Cg) and np.array_equal(Zh, Zg)
+    b = X[:, 0].copy()
+    xh, xg = H.ldiv(b), G.ldiv(b)  # the factors do not travel: the receiver eliminates again, with the same arithmetic
+    assert np.linalg.norm(xh - xg) <= 1e-12 * np.linalg.norm(xh)
+    assert np.linalg.norm(A @ xg - b) / np.linalg.norm(b) < 1e-6
+    # a truncated or foreign buffer is refused
+    bad = H.pack()[:100]
+    with pytest.raises(ValueError):
+        hs.hss.HssMatrix.unpack(bad, complex_)
+    with pytest.raises(ValueError):
+        hs.hss.HssMatrix.unpack(H.pack(), not complex_)
