@@ -161,6 +161,7 @@ def metric_workload(hs, hsdist, dev, name, swlevel, tol, steps):
         "maxrank": int(S.backend.L.hs_maxrank(S.backend._h)), "bytes_factors_GiB": st["bytes_factors"] / 2**30,
         "dense_flops_minimal_count": st["flops_factor"],
     }
+    out["flow"] = S.backend.flow_info()
     # the scenario's acceptance number: right-preconditioned GMRES(30) to 1e-8 with this factorization (test/rungmres.jl:47-48)
     try:
         import importlib
@@ -176,6 +177,42 @@ def metric_workload(hs, hsdist, dev, name, swlevel, tol, steps):
         out["gmres"] = {"error": repr(e)}
     S.backend.L.hs_free(S.backend._h)
     S.backend._h = None
+    del S
+    torch.cuda.empty_cache()
+    # ---- MFMA roofline of THIS workload (BASELINE.json's metric pairs the time with the MFMA utilisation): one more factorization with a HIP
+    # event pair around every launch of the two MFMA kernels -- `gemm_op_kernel<cplx>` (trailing / Schur updates of the fronts, hs_stats) and
+    # `gemm_probs_kernel<cplx>` (every grouped product of the compressions, hs_probs_stats; its flops are counted by the kernel itself)
+    try:
+        import ctypes as C
+
+        L = hs._lib.lib()
+        L.hs_probs_stats_mode(2)
+        Sp = hsdist.StagedSolver(Ap, nd, nd_loc, device=dev, profile=True, **fopts)
+        Sp.numeric()
+        torch.cuda.synchronize(dev)
+        sp = Sp.stats()
+        o3 = (C.c_double * 3)()
+        L.hs_probs_stats(o3)
+        L.hs_probs_stats_mode(0)
+        f_op, t_op, n_op = float(sp["gemm_flops"]), float(sp["t_mfma_kernel"]), int(sp["mfma_kernel_launches"])  # (complex launches are already counted as 8 M N K)
+        f_pr, n_pr, t_pr = float(o3[0]), int(o3[1]), float(o3[2])
+        tot_t = max(t_op + t_pr, 1e-30)
+        ach = (f_op + f_pr) / tot_t / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "gemm_op_kernel + gemm_probs_kernel (v_mfma_f64_16x16x4_f64; complex: 4 real MFMAs per k-step, flops = 8 M N K)",
+            "achieved": ach, "peak": FP64_MFMA_PEAK_DATASHEET, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_DATASHEET, "traffic": None,
+            "gemm_op_kernel": {"flops": f_op, "seconds": t_op, "launches": n_op, "TFLOPs": f_op / max(t_op, 1e-30) / 1e12, "frac": f_op / max(t_op, 1e-30) / 1e12 / FP64_MFMA_PEAK_DATASHEET},
+            "gemm_probs_kernel": {"flops": f_pr, "seconds": t_pr, "launches": n_pr, "TFLOPs": f_pr / max(t_pr, 1e-30) / 1e12, "frac": f_pr / max(t_pr, 1e-30) / 1e12 / FP64_MFMA_PEAK_DATASHEET,
+                                  "note": "launch durations summed over the concurrent compression streams: they may overlap each other and the fronts' kernels"},
+            "factor_s_profiled": float(sp["t_total"]),
+            "share_of_factor_time_in_mfma_kernels": min(tot_t / max(float(sp["t_total"]), 1e-30), 1.0),
+            "executed_over_dense_minimal_flops": (f_op + f_pr) / max(float(st["flops_factor"]), 1.0),
+            "mfma_util_pct_of_factor_time": 100.0 * (f_op + f_pr) / max(float(sp["t_total"]), 1e-30) / 1e12 / FP64_MFMA_PEAK_DATASHEET,
+        }
+        Sp.backend.L.hs_free(Sp.backend._h)
+        Sp.backend._h = None
+    except Exception as e:  # the bench line must not die on the extra
+        out["roofline"] = {"error": repr(e)}
     return out
 
 
@@ -371,6 +408,7 @@ def main():
             roofline["frac_of_measured"] = ach / peak_meas if peak_meas > 0 else None
 
     maxrank_main = int(S.backend.L.hs_maxrank(S.backend._h)) if getattr(S.backend, "_h", None) else None
+    flow_main = S.backend.flow_info() if getattr(S.backend, "_h", None) else None  # what the library did with the options on rank 0
     oneshot = None
     extra_metric = None
     if world == 1:
@@ -415,7 +453,10 @@ def main():
             "config": {"workload": args.workload, "n": int(Ap.shape[0]), "nnz": int(Ap.nnz), "tree_nodes": int(st["nnodes"]),
                        "tree_depth": int(st["nlevels"]), "max_front": [int(st["max_ni"]), int(st["max_nb"])], "nrhs": 1,
                        "compression": "none (swlevel=0)" if args.swlevel == 0 else f"{'matrix-free HSS hand-over' if args.mf else 'low-rank off-diagonal blocks'}, swlevel={args.swlevel} swsize={args.swsize} atol=rtol={args.tol:g} split={args.split} hss_min={args.hss_min} mf={int(args.mf)}",
-                       "partition": f"subtree-per-rank x{world}" + ((" + fronts above the cut over their rank groups (1-D block-cyclic block columns, " + libcomm.kind() + ")") if fopts.get("dist_top") else "")},
+                       "partition": f"subtree-per-rank x{world}" + ((" + fronts above the cut over their rank groups (1-D block-cyclic block columns, " + libcomm.kind() + ")") if fopts.get("dist_top") else
+                                                                      ((" + fronts above the cut on the first rank of their group; the joins ship " +
+                                                                        ("packed HSS generators (hs_schur_pack / hs_schur_unpack)" if (flow_main or {}).get("mf") else "dense Schur complements")) if world > 1 else ""))},
+            "flow": flow_main,
             "factor_s": st["t_total"],
             "residual": res,
             "maxrank": maxrank_main,

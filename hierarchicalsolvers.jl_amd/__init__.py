@@ -10,7 +10,7 @@ from .nesteddissection import (  # noqa: F401
     contigious, parse_elimtree, serialize_elimtree, getinterior, getboundary, flatten_tree, native_symbolic, native_graph_symbolic,
 )
 from . import problems  # noqa: F401
-from .solver import SolverOptions, chkopts, factor, factorize, FactorNode, ldiv, maxrank  # noqa: F401,E402
+from .solver import SolverOptions, chkopts, factor, factorize, FactorNode, ldiv, maxrank, trim  # noqa: F401,E402
 from ._lib import DimensionMismatch, SingularException, DeviceError, UnsupportedError  # noqa: F401,E402
 from . import _lib  # noqa: F401,E402
 from . import dist  # noqa: F401,E402

@@ -14,6 +14,8 @@
 //   hs_numeric_levels assemble + eliminate the owned fronts of a range of tree levels
 //   hs_numeric_end    synchronise, singular-front check, timings
 //   hs_solve_*_levels forward / backward sweeps over a range of levels on a device vector
+#include <chrono>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -187,6 +189,7 @@ struct Exchange {
 #include "hs_comm.h"
 
 struct hs_handle {
+  size_t fac_bytes = 0, inv_bytes = 0, sb_bytes = 0;  // sizes d_fac / d_inv / d_sb were asked for (the arena cache parks them by size)
   bool is_complex = false;
   int64_t n = 0, nnz = 0;
   int nnodes = 0;  // tree nodes (+1 pseudo-node when the root keeps a boundary)
@@ -263,6 +266,70 @@ struct hs_handle {
 static inline int rup(int x, int a) { return (x + a - 1) / a * a; }
 static inline size_t rups(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ------------------------------------------------------------------------------------------------
+// The three big blocks of a factorization -- factor arena (139 GiB at Poisson 128^3), inverse blocks, Schur scratch -- come back from the
+// driver slowly once the process has freed memory of that size before: measured hipMalloc of the 139 GiB arena 1.4 s in a fresh process,
+// 4.9 s after a hipFree of the previous one (tools/oneshot_probe.py; that was the unexplained 5 s between `factor_oneshot_s` and
+// analyze + numeric in round 2).  hs_free therefore parks them in a small process-wide cache and the next hs_analyze / hs_factor_* of a
+// similar size takes them over; hs_trim() (or HS_ARENA_CACHE=0) gives them back.  At most HS_ARENA_SLOTS blocks are parked; an allocation that
+// fails anywhere in the library empties the cache and tries again.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ArenaCache {
+  std::mutex mu;
+  struct Blk { void* p; size_t bytes; };
+  std::vector<Blk> v;
+};
+ArenaCache& arena_cache() {
+  static ArenaCache* c = new ArenaCache();
+  return *c;
+}
+constexpr size_t HS_ARENA_MIN = (size_t)256 << 20;  // smaller blocks are not worth parking
+constexpr size_t HS_ARENA_SLOTS = 4;
+bool arena_cache_on() {
+  static const bool on = !(getenv("HS_ARENA_CACHE") && getenv("HS_ARENA_CACHE")[0] == '0');
+  return on;
+}
+}  // namespace
+extern "C" int64_t hs_arena_trim(void) {  // the parked arenas only (what the block pools of the HSS / low-rank modules call when THEY run out)
+  int64_t freed = 0;
+  ArenaCache& c = arena_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (auto& b : c.v) {
+    (void)hipFree(b.p);
+    freed += (int64_t)b.bytes;
+  }
+  c.v.clear();
+  return freed;
+}
+extern "C" int64_t hs_trim(void) { return hs_arena_trim() + hs_hss_trim(); }  // device bytes given back to the driver
+static void* arena_take(size_t bytes) {
+  if (!arena_cache_on() || bytes < HS_ARENA_MIN) return nullptr;
+  ArenaCache& c = arena_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  size_t best = c.v.size();
+  for (size_t i = 0; i < c.v.size(); ++i)
+    if (c.v[i].bytes >= bytes && c.v[i].bytes <= bytes + bytes / 8 && (best == c.v.size() || c.v[i].bytes < c.v[best].bytes)) best = i;
+  if (best == c.v.size()) return nullptr;
+  void* p = c.v[best].p;
+  c.v.erase(c.v.begin() + (long)best);
+  return p;
+}
+static void arena_give(void* p, size_t bytes) {
+  if (!p) return;
+  if (!arena_cache_on() || bytes < HS_ARENA_MIN) {
+    (void)hipFree(p);
+    return;
+  }
+  ArenaCache& c = arena_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  c.v.push_back({p, bytes});
+  while (c.v.size() > HS_ARENA_SLOTS) {  // the oldest goes back to the driver
+    (void)hipFree(c.v.front().p);
+    c.v.erase(c.v.begin());
+  }
+}
+
 static void free_lowrank_any(hs_handle* h);
 static void free_hss_any(hs_handle* h);
 static void free_mfd_buffers(hs_handle* h);
@@ -277,7 +344,10 @@ static void free_handle(hs_handle* h) {
   free_mfd_buffers(h);
   free_hss_any(h);
   free_lowrank_any(h);
-  void* ptrs[] = {h->d_fac,   h->d_inv, h->d_sb,    h->d_int, h->d_tmpi, h->d_colptr, h->d_rowval, h->d_nz,
+  arena_give(h->d_fac, h->fac_bytes);
+  arena_give(h->d_inv, h->inv_bytes);
+  arena_give(h->d_sb, h->sb_bytes);
+  void* ptrs[] = {h->d_int, h->d_tmpi, h->d_colptr, h->d_rowval, h->d_nz,
                   h->d_nodes, h->d_sc,  h->d_solve, h->d_w1,  h->d_w2,   h->d_part,   h->d_b,   h->d_owned,
                   h->d_rowptr, h->d_colind, h->d_tperm, h->d_nzr, h->d_lpos};
   for (void* p : ptrs)
@@ -536,10 +606,21 @@ static double front_flops(double ni, double nb) { return (2.0 / 3.0) * ni * ni *
 static void dmalloc(void** p, size_t bytes, const char* what) {
   if (bytes == 0) bytes = 256;
   if (hipMalloc(p, bytes) != hipSuccess) {
-    *p = nullptr;
     (void)hipGetLastError();
-    HS_FAIL(HS_ERR_NOMEM, 0, "hipMalloc of %.3f GiB for %s failed", bytes / 1073741824.0, what);
+    (void)hs_trim();  // parked arenas and the recycled blocks of the HSS / low-rank modules go back to the driver first
+    if (hipMalloc(p, bytes) != hipSuccess) {
+      *p = nullptr;
+      (void)hipGetLastError();
+      HS_FAIL(HS_ERR_NOMEM, 0, "hipMalloc of %.3f GiB for %s failed", bytes / 1073741824.0, what);
+    }
   }
+}
+// one of the three big blocks: a parked one of about this size if there is one
+static void dmalloc_arena(void** p, size_t* held, size_t bytes, const char* what) {
+  bytes = std::max<size_t>(bytes, 256);
+  *p = arena_take(bytes);
+  if (!*p) dmalloc(p, bytes, what);
+  *held = bytes;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -560,6 +641,15 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
   if (!plan_only) require_device();
 
   hs_handle* h = new hs_handle();
+  const bool vta = getenv("HS_VERBOSE_ONESHOT") != nullptr && !plan_only;  // diagnostics: wall time of the stages of the analysis
+  auto twa = std::chrono::steady_clock::now();
+  auto lapa = [&](const char* what) {
+    if (!vta) return;
+    (void)hipDeviceSynchronize();
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[hs analyze] %-40s %8.3f s\n", what, std::chrono::duration<double>(now - twa).count());
+    twa = now;
+  };
   try {
     h->is_complex = sizeof(T) == 16;
     h->n = n;
@@ -774,6 +864,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
       return h;
     }
 
+    lapa("plan + layout (host)");
     HS_HIP(hipStreamCreate(&h->stream));
     hs_create_lookahead_streams(&h->stream_la, &h->stream2m, &h->stream2);
     HS_HIP(hipEventCreate(&h->ev0));
@@ -808,10 +899,15 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
       HS_HIP(hipEventCreateWithFlags(&h->ev_ca, hipEventDisableTiming));
       HS_HIP(hipEventCreateWithFlags(&h->ev_cb, hipEventDisableTiming));
     }
-    dmalloc(&h->d_fac, fac * sizeof(T), "the factors (LF/UR)");
-    dmalloc(&h->d_inv, inv * sizeof(T), "the inverse diagonal blocks");
+    lapa("streams, events");
+    dmalloc_arena(&h->d_fac, &h->fac_bytes, fac * sizeof(T), "the factors (LF/UR)");
+    lapa("hipMalloc of the factor arena");
+    dmalloc_arena(&h->d_inv, &h->inv_bytes, inv * sizeof(T), "the inverse diagonal blocks");
+    lapa("hipMalloc of the inverse blocks");
     HS_HIP(hipMemset(h->d_inv, 0, inv * sizeof(T)));  // identity padding / unwritten corners must read as zero
-    dmalloc(&h->d_sb, sb_total * sizeof(T), "the Schur-complement scratch");
+    lapa("memset of the inverse blocks");
+    dmalloc_arena(&h->d_sb, &h->sb_bytes, sb_total * sizeof(T), "the Schur-complement scratch");
+    lapa("hipMalloc of the Schur scratch");
     dmalloc((void**)&h->d_int, ints * sizeof(int), "index lists");
     const size_t tmpi_total = tmpi + 2 * (size_t)h->nnodes + 2 * (size_t)n;
     dmalloc((void**)&h->d_tmpi, tmpi_total * sizeof(int), "pivoting scratch");
@@ -884,6 +980,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
       mf_couplings(h, n, colptr, rowval);
       mf_build_csr(h, n, colptr, rowval);
     }
+    lapa("pattern, index lists, cmaps (host + upload)");
     if (nranks > 1) {  // the DOFs this rank eliminates, as one index list
       std::vector<int> owned;
       for (int i = 0; i < h->nnodes; ++i)
@@ -969,6 +1066,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
       if (!hsc.empty()) HS_HIP(hipMemcpy(h->d_sc, hsc.data(), hsc.size() * sizeof(ScatterDesc<T>), hipMemcpyHostToDevice));
       if (!sn.empty()) HS_HIP(hipMemcpy(h->d_solve, sn.data(), sn.size() * sizeof(SolveNode<T>), hipMemcpyHostToDevice));
     }
+    lapa("descriptors");
     dmalloc(&h->d_w1, (size_t)(woff + 1) * sizeof(T), "solve workspace");
     dmalloc(&h->d_w2, (size_t)(woff + 1) * sizeof(T), "solve workspace");
     dmalloc(&h->d_part, (size_t)(poff + 1) * sizeof(T), "solve partial sums");
@@ -1429,14 +1527,27 @@ static int factor_entry(int64_t n, const int64_t* colptr, const int64_t* rowval,
   hs_handle* h = nullptr;
   try {
     if (!nzval) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: nzval == NULL");
+    const bool vt = getenv("HS_VERBOSE_ONESHOT") != nullptr;  // diagnostics: wall time of the stages of the one-shot entry point
+    auto tw = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!vt) return;
+      auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[hs oneshot] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - tw).count());
+      tw = now;
+    };
     h = analyze_impl<T>(n, colptr, rowval, tree, opts, 0, 1);
+    lap("analyze (plan, uploads, arena)");
     numeric_begin<T>(h, nzval, 0);
+    lap("numeric_begin (values)");
     numeric_levels<T>(h, (int)h->levels.size() - 1, 0);
+    lap("numeric_levels (enqueue)");
     numeric_end(h);
+    lap("numeric_end (device done)");
     if (!h->sb_kept) {  // one-shot path: the Schur scratch is not needed again
-      (void)hipFree(h->d_sb);
+      arena_give(h->d_sb, h->sb_bytes);
       h->d_sb = nullptr;
     }
+    lap("free of the Schur scratch");
     *out = h;
     return HS_OK;
   } catch (const HsError& e) {

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64) void idx_compose_kernel(const IdxJob* __restric
 // classes of powers of two, blocks above 64 MiB go straight back to the driver.  The cache is never destroyed (its blocks return to
 // the driver with the process; a static destructor would run after the HIP runtime has shut down) and is guarded by a mutex:
 // distinct handles may be used from different threads.
+extern "C" int64_t hs_arena_trim(void);
 struct BlockCache {
   std::multimap<size_t, void*> free_;
   std::mutex mu;
@@ -315,8 +316,12 @@ struct Pool {
       }
       if (hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
-        hs_set_error(HS_ERR_NOMEM, 0, "hipMalloc of %zu bytes failed (HSS module)", bytes);
-        throw (int)HS_ERR_NOMEM;
+        (void)hs_arena_trim();  // the arenas hs_free parked (hs_api.hip): up to a whole factorization's worth of memory
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+          (void)hipGetLastError();
+          hs_set_error(HS_ERR_NOMEM, 0, "hipMalloc of %zu bytes failed (HSS module)", bytes);
+          throw (int)HS_ERR_NOMEM;
+        }
       }
     }
     v.push_back({p, bytes});

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ sr
 // ------------------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------------------
+extern "C" int64_t hs_arena_trim(void);
 namespace {
 struct LrCache {
   std::mutex mu;
@@ -107,6 +108,11 @@ int hs_lr_alloc(void** out, size_t bytes) {
       c->held = 0;
     }
     e = hipMalloc(out, cls);
+    if (e != hipSuccess) {  // last: the arenas hs_free parked (hs_api.hip)
+      (void)hipGetLastError();
+      (void)hs_arena_trim();
+      e = hipMalloc(out, cls);
+    }
     if (e != hipSuccess) {
       (void)hipGetLastError();
       *out = nullptr;

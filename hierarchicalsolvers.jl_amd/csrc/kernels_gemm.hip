@@ -19,6 +19,8 @@
 //
 // Complex: planar split when staging (re / im images in LDS), 4 real MFMAs per k-step
 // (re += ar*br - ai*bi, im += ar*bi + ai*br); 128x64 tile, wave tile 64x32.
+#include <mutex>
+#include <vector>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -635,12 +637,16 @@ __global__ __launch_bounds__(256, 2) void trsm_inv_kernel(const NodeDesc<T>* __r
   gemm_dispatch<T>(p, false, smem);
 }
 
+// Accounting of the grouped products (hs_probs_stats, include/hs_kernels.h): the descriptors live on the device, so the kernel itself adds
+// the real flops of every problem (one atomic per problem and launch, only while the accounting is on: bit 1 of `minus`)
+__device__ double g_probs_flops;
 template <class T>
 __global__ __launch_bounds__(256, 2) void gemm_probs_kernel(const GemmProb<T>* __restrict__ probs, int minus) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   GemmProb<T> p = probs[blockIdx.y];
   if (p.M <= 0 || p.N <= 0) return;
-  gemm_dispatch<T>(p, minus != 0, smem);
+  if ((minus & 2) && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_probs_flops, (sizeof(T) == 16 ? 8.0 : 2.0) * p.M * (double)p.N * p.K);
+  gemm_dispatch<T>(p, (minus & 1) != 0, smem);
 }
 // Problem lists that cannot fill the chip with 128 x 128 tiles (launch_gemm_probs decides): what such a launch costs is the LENGTH of a
 // tile's K loop (1.7 us per 16 columns for a lone workgroup), so the work is cut into 64 x 64 tiles -- a quarter of the MFMAs per K-step,
@@ -649,6 +655,8 @@ __global__ __launch_bounds__(256, 2) void gemm_probs_skinny_kernel(const GemmPro
   extern __shared__ __attribute__((aligned(16))) double smem[];
   GemmProb<double> p = probs[blockIdx.y];
   if (p.M <= 0 || p.N <= 0) return;
+  if ((minus & 2) && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_probs_flops, 2.0 * p.M * (double)p.N * p.K);
+  minus &= 1;
   if (p.M <= 64 && p.N > 64) {
     const int tn_ = (p.N + 127) / 128;
     for (int bid = blockIdx.x; bid < tn_; bid += gridDim.x) {
@@ -719,9 +727,69 @@ void launch_gemm_op(const NodeDesc<T>* dnodes, int nbatch, int maxM, int maxN, c
     hipLaunchKernelGGL(gemm_op_kernel<T>, dim3(tiles, nbatch), dim3(256), lds_bytes, s, dnodes, op);
 }
 
+// hs_probs_stats: flops (counted by the kernels), launches and -- with timing on -- the summed launch durations of the grouped products,
+// process-wide (they are issued from the HSS module, the low-rank compressions and the matrix-free fronts, on several streams)
+namespace {
+struct ProbsAcc {
+  std::mutex mu;
+  int mode = 0;  // 0: off, 1: flops + launches, 2: + a HIP event pair around every launch
+  long long launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+ProbsAcc& probs_acc() {
+  static ProbsAcc* a = new ProbsAcc();
+  return *a;
+}
+}  // namespace
+extern "C" int hs_probs_stats_mode(int mode) {  // resets the counters
+  ProbsAcc& a = probs_acc();
+  std::lock_guard<std::mutex> lk(a.mu);
+  (void)hipDeviceSynchronize();
+  for (auto& e : a.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  a.ev.clear();
+  a.launches = 0;
+  a.mode = mode;
+  const double z = 0.0;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_probs_flops), &z, sizeof z) == hipSuccess ? 0 : -6;
+}
+extern "C" int hs_probs_stats(double* out3) {  // {real flops executed, launches, summed launch seconds (0 without timing)}
+  if (!out3) return -1;
+  ProbsAcc& a = probs_acc();
+  std::lock_guard<std::mutex> lk(a.mu);
+  if (hipDeviceSynchronize() != hipSuccess) return -6;
+  double fl = 0.0, ms = 0.0;
+  if (hipMemcpyFromSymbol(&fl, HIP_SYMBOL(g_probs_flops), sizeof fl) != hipSuccess) return -6;
+  for (auto& e : a.ev) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) ms += t;
+  }
+  out3[0] = fl; out3[1] = (double)a.launches; out3[2] = ms * 1e-3;
+  return 0;
+}
+
 template <class T>
 void launch_gemm_probs(const GemmProb<T>* dprobs, int nprob, int maxM, int maxN, int minus, hipStream_t s) {
   if (nprob <= 0 || maxM <= 0 || maxN <= 0) return;
+  minus = minus ? 1 : 0;
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  {
+    ProbsAcc& a = probs_acc();
+    if (a.mode) {  // (read without the lock: switched only between factorizations)
+      std::lock_guard<std::mutex> lk(a.mu);
+      a.launches++;
+      minus |= 2;
+      if (a.mode >= 2 && hipEventCreate(&pe0) == hipSuccess && hipEventCreate(&pe1) == hipSuccess) {
+        (void)hipEventRecord(pe0, s);
+        a.ev.push_back({pe0, pe1});
+      } else {
+        pe1 = nullptr;
+      }
+    }
+  }
+  struct Rec {  // the closing event is recorded on every exit path
+    hipEvent_t e; hipStream_t s;
+    ~Rec() { if (e) (void)hipEventRecord(e, s); }
+  } rec{pe1, s};
   int tiles = ((maxM + BM - 1) / BM) * ((maxN + TileCfg<T>::bn - 1) / TileCfg<T>::bn);
   constexpr int lds_bytes = TileCfg<T>::smem_doubles * 8;
   static bool attr_set = false;

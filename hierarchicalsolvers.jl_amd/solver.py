@@ -272,6 +272,12 @@ def factor(A, nd, nd_loc, opts=None, **kw):
 factorize = factor  # BASELINE.json's north star uses this name
 
 
+def trim():
+    """Give the device blocks the library parks between factorizations (the factor arena of the last freed handle, the recycled blocks of the
+    HSS / low-rank modules) back to the driver; returns the bytes released (``hs_trim``, include/hs_solver.h)."""
+    return int(_lib.lib().hs_trim())
+
+
 def ldiv(*args):
     """``ldiv!(F, B)`` / ``ldiv!(C, F, B)`` (factornode.jl:62-74): ``C = F^-1 B`` for a vector or an
     ``n x nrhs`` matrix.  The 2-argument form returns a new array like the reference (which

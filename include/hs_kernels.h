@@ -45,6 +45,14 @@ int hsk_lowrank_z(int64_t rows, int64_t cols, const double* X, double atol, doub
  * HSS cluster tree splits its index range.  perm_out[new position] = position in `ids` (0-based). */
 int hsk_bisect_perm(int64_t n, const int64_t* colptr, const int64_t* rowval, int64_t ni, const int64_t* ids, int64_t* perm_out);
 
+/* Accounting of the GROUPED MFMA products (`gemm_probs_kernel`: every product of the HSS module, of the low-rank compressions and of the
+ * matrix-free fronts -- the flops of the compressed branch that `hs_stats.gemm_flops` (the fronts' `gemm_op_kernel`) does not see).
+ *   hs_probs_stats_mode(0 | 1 | 2) : off / count flops and launches / also time every launch with a HIP event pair; resets the counters
+ *   hs_probs_stats(out3)           : {real flops executed (complex: 8 M N K), launches, summed launch seconds}; synchronises the device
+ * Process-wide (the products are issued from several host threads and streams). */
+int hs_probs_stats_mode(int mode);
+int hs_probs_stats(double* out3);
+
 /* Measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on every CU (roofline denominator). */
 double hsk_mfma_f64_peak(int waves_per_simd, int iters);
 /* The same issue loop on random operands that change while it runs: the rate at the clock the chip holds under such data (DVFS). */

@@ -226,6 +226,12 @@ int hs_node_ranks(const hs_handle* F, int64_t node, int64_t* rank_L, int64_t* ra
 int hs_is_complex(const hs_handle* F);  /* eltype(F) == ComplexF64 */
 int64_t hs_size(const hs_handle* F);    /* n */
 void hs_free(hs_handle* F);
+/* hs_free parks the three big device blocks of a factorization (factor arena, inverse blocks, Schur scratch; blocks >= 256 MiB, at most four)
+ * in a process-wide cache, and the next hs_analyze / hs_factor_* of about the same size takes them over: the driver hands out 139 GiB in
+ * 1.4 s in a fresh process but needs 4.9 s once memory of that size has been freed before (measured, MI355X / ROCm 7.2).  hs_trim gives the
+ * parked blocks and the recycled blocks of the HSS / low-rank modules back to the driver and returns their bytes (call it with nothing in
+ * flight; a failing allocation inside the library does it by itself).  HS_ARENA_CACHE=0 in the environment turns the parking off. */
+int64_t hs_trim(void);
 const char* hs_last_error(void);
 int64_t hs_last_error_info(void); /* e.g. node id of a singular front */
 
