@@ -115,7 +115,7 @@ def cpu_baseline(sample="poisson3d_32", dev=None):
     return out
 
 
-def pmc_traffic(workload, launches, round_tag="r02"):
+def pmc_traffic(workload, launches, round_tag="r03"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS round (tools/pmc_bench.sh; counters cannot be read
     from inside the timed process).  Refused -- null plus the reason -- when the file is missing or was measured on a different launch count."""
     pmc = os.path.join(ROOT, "profiles", "%s_%s_gemm_pmc_traffic.json" % (round_tag, workload))

@@ -148,6 +148,7 @@ struct GemmOp {
                    // 3..6: the 256-row base case through inv256L / inv256U, as two in-place half products (resolve_op)
                    // 7, 8: rows [r0, ..) of the 256 columns from k0 on times inv256U[k0/256], in place: the multipliers of the rows BELOW a
                    //       256-wide diagonal block once that block is factored (Sched::lu_rec, optimistic pivoting): 7 = columns 128.. (first), 8 = columns 0..127
+                   // 16 + q: the same for 64-column tiles (ComplexF64): column block q of the group from all blocks <= q, run for q = 3, 2, 1, 0
   int cap;         // > 0: launch at most this many workgroups per front (they walk the tiles): leaves CU slots free for a
                    // concurrent stream (the look-ahead panel chain); 0: one workgroup per tile
   int prio;        // 1: raise the waves' issue priority (s_setprio): panel work of the look-ahead side stream

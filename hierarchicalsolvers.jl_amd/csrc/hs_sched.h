@@ -246,11 +246,13 @@ struct Sched {
   // on the 256 x 256 block alone -- every kernel of it one workgroup, which finds a slot next to a running GEMM at once, where the
   // 128-workgroup L21 step of a 32,768-row front waited ~80 us for its slots -- and the multipliers of all rows below follow as
   // L_below = A_below * inv(U_group): two in-place MFMA products with the stored inverse of the group's U (GemmOp::ainv 7, 8), which
-  // also check the growth bound of the rows partial pivoting could have picked.  Float64 only (the complex tile is 64 columns wide: the
-  // in-place product would need three passes); the tournament path keeps the full-height panels.
+  // also check the growth bound of the rows partial pivoting could have picked.  ComplexF64 (round 3; its tile is 64 columns wide): four
+  // in-place products, one per 64-column block from the right (GemmOp::ainv 19, 18, 17, 16) -- at Helmholtz 112^3 the full-height
+  // `panel_l21_kernel<cplx>` was 14 % of the device time (0.78 s per factorization: one row per thread, 256 VGPRs, 2,048 FP64 FMAs per row
+  // and panel on the vector pipe).  The tournament path keeps the full-height panels.
   bool diag_first() const {
-    static const int on = env_int("HS_DIAG_FIRST", 1);
-    return on && optimistic && sn && sizeof(T) == 8 && rlim == HS_BIG;
+    static const int on = env_int("HS_DIAG_FIRST", 1), on_z = env_int("HS_DIAG_FIRST_Z", 1);
+    return on && (sizeof(T) == 8 || on_z) && optimistic && sn && rlim == HS_BIG;
   }
   void lu_rec(int c0, int c1) {
     if (c0 >= maxni) return;
@@ -261,12 +263,23 @@ struct Sched {
       launch_inv256<T>(sn, nbatch, maxni, s, c0 / 256);
       const int r0 = c0 + 256;
       if (r0 < maxm) {
-        for (int code : {7, 8}) {
-          GemmOp op{HS_MAT_LF, HS_MAT_LF, r0, HS_BIG, c0, c1, c0, c1, code, 0, hiprio};
-          hipEvent_t e0 = pf->begin(s);
-          launch_gemm_op<T>(dn, nbatch, maxm - r0, 128, op, s);
-          pf->end(e0, HS_CAT_TRSM, s);
-          dbg("l_below", c0, r0, code);
+        if (sizeof(T) == 8) {
+          for (int code : {7, 8}) {
+            GemmOp op{HS_MAT_LF, HS_MAT_LF, r0, HS_BIG, c0, c1, c0, c1, code, 0, hiprio};
+            hipEvent_t e0 = pf->begin(s);
+            launch_gemm_op<T>(dn, nbatch, maxm - r0, 128, op, s);
+            pf->end(e0, HS_CAT_TRSM, s);
+            dbg("l_below", c0, r0, code);
+          }
+        } else {
+          const int wl = std::min(256, maxni - c0);
+          for (int q = (wl - 1) / 64; q >= 0; --q) {
+            GemmOp op{HS_MAT_LF, HS_MAT_LF, r0, HS_BIG, c0, c1, c0, c1, 16 + q, 0, hiprio};
+            hipEvent_t e0 = pf->begin(s);
+            launch_gemm_op<T>(dn, nbatch, maxm - r0, 64, op, s);
+            pf->end(e0, HS_CAT_TRSM, s);
+            dbg("l_below", c0, r0, 16 + q);
+          }
         }
       }
       return;
