@@ -75,11 +75,23 @@ struct RcclComm : hs_comm {
     for (auto& p : recvs) any = any || p.bytes > 0;
     if (!any) return;
     HS_NCCL(R.GroupStart());
+    // a failing ncclSend / ncclRecv must not leave the communicator inside an open group (every later call on it would be queued into that
+    // group and never run): the group is closed before the error is raised
+    ncclResult_t bad = ncclSuccess;
+    const char* what = "";
     for (auto& p : sends)
-      if (p.bytes > 0) HS_NCCL(R.Send(p.ptr, p.bytes, ncclChar, p.peer, comm, s));
+      if (p.bytes > 0 && bad == ncclSuccess) {
+        bad = R.Send(p.ptr, p.bytes, ncclChar, p.peer, comm, s);
+        what = "ncclSend";
+      }
     for (auto& p : recvs)
-      if (p.bytes > 0) HS_NCCL(R.Recv(p.ptr, p.bytes, ncclChar, p.peer, comm, s));
-    HS_NCCL(R.GroupEnd());
+      if (p.bytes > 0 && bad == ncclSuccess) {
+        bad = R.Recv(p.ptr, p.bytes, ncclChar, p.peer, comm, s);
+        what = "ncclRecv";
+      }
+    const ncclResult_t endr = R.GroupEnd();
+    if (bad != ncclSuccess) HS_COMM_FAIL(HS_ERR_DEVICE, "%s failed inside a grouped transfer: %s", what, R.GetErrorString(bad));
+    if (endr != ncclSuccess) HS_COMM_FAIL(HS_ERR_DEVICE, "ncclGroupEnd failed: %s", R.GetErrorString(endr));
   }
 };
 
@@ -229,18 +241,46 @@ __global__ void hs_comm_fill_kernel(unsigned char* p, size_t n, unsigned seed) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < n) p[i] = (unsigned char)((i * 2654435761u + seed) >> 7);
 }
+namespace {
+// device buffers, a stream and events of the self-test / bandwidth probe, released on every exit path (a transfer or a HIP call that throws used
+// to leak them: bench.py runs both on every multi-rank start and carries on after a failure)
+struct ProbeRes {
+  std::vector<void*> bufs;
+  hipStream_t s = nullptr;
+  std::vector<hipEvent_t> evs;
+  ~ProbeRes() {
+    if (s) (void)hipStreamSynchronize(s);
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    for (void* p : bufs) (void)hipFree(p);
+    if (s) (void)hipStreamDestroy(s);
+  }
+  unsigned char* buf(size_t bytes) {
+    void* p = nullptr;
+    HS_HIP(hipMalloc(&p, bytes));
+    bufs.push_back(p);
+    return (unsigned char*)p;
+  }
+  hipEvent_t event() {
+    hipEvent_t e = nullptr;
+    HS_HIP(hipEventCreate(&e));
+    evs.push_back(e);
+    return e;
+  }
+};
+}  // namespace
+
 extern "C" int hs_comm_selftest(hs_comm* c, int64_t bytes) {
   HS_COMM_GUARD(
-      if (!c || bytes <= 0) HS_COMM_FAIL(HS_ERR_ARGUMENT, "ArgumentError: communicator / byte count"); unsigned char* d = nullptr; unsigned char* r = nullptr;
-      HS_HIP(hipMalloc((void**)&d, bytes)); HS_HIP(hipMalloc((void**)&r, bytes)); hipStream_t s; HS_HIP(hipStreamCreate(&s));
+      if (!c || bytes <= 0) HS_COMM_FAIL(HS_ERR_ARGUMENT, "ArgumentError: communicator / byte count");
+      ProbeRes R; unsigned char* d = R.buf((size_t)bytes); unsigned char* r = R.buf((size_t)bytes); HS_HIP(hipStreamCreate(&R.s)); hipStream_t s = R.s;
       const int next = (c->rank + 1) % c->nranks, prev = (c->rank - 1 + c->nranks) % c->nranks;
       hs_comm_fill_kernel<<<(unsigned)((bytes + 255) / 256), 256, 0, s>>>(d, (size_t)bytes, 17u * (unsigned)c->rank + 1u);
       HS_HIP(hipMemsetAsync(r, 0, bytes, s));
       c->transfer({HsPiece{next, d, (size_t)bytes}}, {HsPiece{prev, r, (size_t)bytes}}, s);
       hs_comm_fill_kernel<<<(unsigned)((bytes + 255) / 256), 256, 0, s>>>(d, (size_t)bytes, 17u * (unsigned)prev + 1u);  // what prev sent
       std::vector<unsigned char> a(bytes), b(bytes); HS_HIP(hipMemcpyAsync(a.data(), d, bytes, hipMemcpyDeviceToHost, s));
-      HS_HIP(hipMemcpyAsync(b.data(), r, bytes, hipMemcpyDeviceToHost, s)); HS_HIP(hipStreamSynchronize(s)); (void)hipFree(d); (void)hipFree(r);
-      (void)hipStreamDestroy(s); if (memcmp(a.data(), b.data(), bytes) != 0) HS_COMM_FAIL(HS_ERR_DEVICE, "communicator self-test: received bytes differ from the sender's"));
+      HS_HIP(hipMemcpyAsync(b.data(), r, bytes, hipMemcpyDeviceToHost, s)); HS_HIP(hipStreamSynchronize(s));
+      if (memcmp(a.data(), b.data(), bytes) != 0) HS_COMM_FAIL(HS_ERR_DEVICE, "communicator self-test: received bytes differ from the sender's"));
 }
 
 // Point-to-point rate of the transport: `reps` ring shifts of `bytes` bytes (rank r -> r+1), device to device, timed with HIP events on
@@ -248,13 +288,13 @@ extern "C" int hs_comm_selftest(hs_comm* c, int64_t bytes) {
 extern "C" int hs_comm_bandwidth(hs_comm* c, int64_t bytes, int64_t reps, double* gbps) {
   HS_COMM_GUARD(
       if (!c || bytes <= 0 || reps <= 0 || !gbps) HS_COMM_FAIL(HS_ERR_ARGUMENT, "ArgumentError: communicator / sizes"); *gbps = 0.0;
-      if (c->nranks < 2) return HS_OK; unsigned char* d = nullptr; unsigned char* r = nullptr; HS_HIP(hipMalloc((void**)&d, bytes));
-      HS_HIP(hipMalloc((void**)&r, bytes)); hipStream_t s; HS_HIP(hipStreamCreate(&s)); hipEvent_t e0, e1; HS_HIP(hipEventCreate(&e0)); HS_HIP(hipEventCreate(&e1));
+      if (c->nranks < 2) return HS_OK;
+      ProbeRes R; unsigned char* d = R.buf((size_t)bytes); unsigned char* r = R.buf((size_t)bytes); HS_HIP(hipStreamCreate(&R.s)); hipStream_t s = R.s;
+      hipEvent_t e0 = R.event(); hipEvent_t e1 = R.event();
       HS_HIP(hipMemsetAsync(d, 1, bytes, s)); const int next = (c->rank + 1) % c->nranks, prev = (c->rank - 1 + c->nranks) % c->nranks;
       c->transfer({HsPiece{next, d, (size_t)bytes}}, {HsPiece{prev, r, (size_t)bytes}}, s);  // warm-up: connections are set up on first use
       HS_HIP(hipStreamSynchronize(s)); HS_HIP(hipEventRecord(e0, s));
       for (int64_t k = 0; k < reps; ++k) c->transfer({HsPiece{next, d, (size_t)bytes}}, {HsPiece{prev, r, (size_t)bytes}}, s);
       HS_HIP(hipEventRecord(e1, s)); HS_HIP(hipStreamSynchronize(s)); float ms = 0.f; HS_HIP(hipEventElapsedTime(&ms, e0, e1));
-      if (ms > 0.f) *gbps = (double)bytes * (double)reps / (ms * 1e-3) / 1e9; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d); (void)hipFree(r);
-      (void)hipStreamDestroy(s));
+      if (ms > 0.f) *gbps = (double)bytes * (double)reps / (ms * 1e-3) / 1e9);
 }

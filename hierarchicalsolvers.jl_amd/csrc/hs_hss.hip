@@ -16,6 +16,7 @@
 //   * triangular solves with blocks of right-hand sides: the fronts' TRSM-by-inverse-blocks (laswp / trsm_rec / utrsm_rec).
 // New kernels here are the HBM-bound movers: row gather / scatter, indexed sub-matrix gather (also the transposes),
 // the interpolation matrices T = L21 * L11^-1 from the packed LU of the samples, index composition, Gaussian fill.
+#include <exception>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -240,7 +241,14 @@ struct Pool {
   explicit Pool(BlockCache* c) : cache(c) {}
   Pool(const Pool&) = delete;
   Pool& operator=(const Pool&) = delete;
-  ~Pool() { clear(); }
+  // the stream the pool's blocks are used on (optional).  Every user synchronises it before its pool dies on the NORMAL path; when an
+  // exception unwinds past the pool, work may still be in flight on blocks that are about to be recycled -- possibly to the other
+  // compression thread (mf_parallel): wait for the stream first
+  hipStream_t guard = nullptr;
+  ~Pool() {
+    if (guard && std::uncaught_exceptions() > 0) (void)hipStreamSynchronize(guard);
+    clear();
+  }
   void clear() {
     if (!hv.empty()) {
       PinnedCache* pc = pinned_cache();
@@ -1025,6 +1033,7 @@ bool compress_fixed(HssT<T>& H, std::vector<CBlock<T>>& cb, int k, BlockOp<T>* b
   const int F = (int)cb.size();
   hipStream_t s = H.s;
   Pool tmp(global_cache());  // samples and everything else that dies with this attempt
+  tmp.guard = s;
   static const bool vtime = getenv("HS_HSS_VERBOSE") != nullptr;  // diagnostics: wall time of every phase (adds synchronisations)
   auto vt0 = std::chrono::steady_clock::now();
   auto vlap = [&](const char* what, int lv) {

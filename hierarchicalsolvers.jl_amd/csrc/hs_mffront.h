@@ -153,7 +153,10 @@ static void free_mfd_buffers(hs_handle* h) {
   }
 }
 
-static hs_hss_options mf_options(const hs_handle* h, int node, double scale, int64_t first_split, int last_k, int n) {
+// rank_L: rank(L) of the front whose Schur complement is being compressed, or 0.  SolverOptions.kest < 0 (the reference's default, -1) means
+// "start the adaptive compression of S with ceil(rank(L) / 2) samples" (src/factorization.jl:102-104); a front without a low-rank L (a
+// flagged leaf, the blocks of D) starts from 4 sqrt(n).  A re-factorization of the same handle starts from the count the last one ended with.
+static hs_hss_options mf_options(const hs_handle* h, int node, double scale, int64_t first_split, int last_k, int n, int rank_L = 0) {
   hs_hss_options o;
   hs_hss_options_default(&o);
   o.leafsize = mf_hss_leaf(h->opts);
@@ -162,6 +165,7 @@ static hs_hss_options mf_options(const hs_handle* h, int node, double scale, int
   o.rtol = h->opts.rtol * scale;
   int64_t k0 = 128;
   while (k0 < 4.0 * std::sqrt((double)n)) k0 *= 2;
+  if (h->opts.kest < 0 && rank_L > 0) k0 = std::max<int64_t>(64, ((rank_L + 1) / 2 + 31) / 32 * 32);  // factorization.jl:102-104
   o.kest = last_k > 0 ? last_k : (h->opts.kest > 0 ? h->opts.kest : k0);
   o.seed = h->opts.seed + 31 * (int64_t)node;
   return o;
@@ -239,7 +243,7 @@ static void mf_compress_schur_dense(hs_handle* h, int id, const T* SB, int lds, 
                                     hipStream_t stream) {
   NodeH& x = h->nodes[id];
   const int64_t fs = (x.n1p > 0 && x.n1p < x.nb) ? x.n1p : 0;
-  hs_hss_options o = mf_options(h, id, 1.0, fs, x.last_ks, x.nb);
+  hs_hss_options o = mf_options(h, id, 1.0, fs, x.last_ks, x.nb, (C_ && Z) ? r1 : 0);
   hs_hss* H = nullptr;
   const int st = h->is_complex ? hs_hss_compress_lru_z(x.nb, (const double*)SB, lds, (const double*)C_, ldc, (const double*)M, ldm, (const double*)Z, ldz, r1, r2, 1,
                                                        x.sperm.data(), &o, stream, &H)
@@ -302,7 +306,7 @@ static void mf_compress_schur_dense_group(hs_handle* h, const std::vector<MfSchu
     const MfSchurArgs<T>& q = a[t];
     NodeH& x = h->nodes[q.id];
     const int64_t fs = (x.n1p > 0 && x.n1p < x.nb) ? x.n1p : 0;
-    opt[t] = mf_options(h, q.id, 1.0, fs, x.last_ks, x.nb);
+    opt[t] = mf_options(h, q.id, 1.0, fs, x.last_ks, x.nb, (q.C && q.Z) ? q.r1 : 0);
     po[t] = &opt[t];
     n[t] = x.nb; B[t] = (const double*)q.SB; ldb[t] = q.lds;
     Cp[t] = (const double*)q.C; ldc[t] = q.ldc; Mp[t] = (const double*)q.M; ldm[t] = q.ldm; Zp[t] = (const double*)q.Z; ldz[t] = q.ldz;
@@ -753,7 +757,7 @@ static void factor_mf_fronts(hs_handle* h, const int* ids, int count) {
     hs_hss_blockop opb{ch1.n2, ch2.n2, ch1.a22, ch2.a22, gid.data() + x.ni, &As, (int32_t*)h->d_lpos};
     if (x.s_hss) {
       const int64_t fs = (x.n1p > 0 && x.n1p < x.nb) ? x.n1p : 0;
-      hs_hss_options o = mf_options(h, id, 1.0, fs, x.last_ks, x.nb);
+      hs_hss_options o = mf_options(h, id, 1.0, fs, x.last_ks, x.nb, rL);
       hs_hss* Sh = nullptr;
       mf_check(h->is_complex ? hs_hss_compress_blockop_z(&opb, (const double*)lrL->Cd, lrL->ldc, (const double*)Mm, ldm, (const double*)lrR->Z, lrR->ldz, upd ? rL : 0,
                                                          upd ? rR : 0, x.sperm.data(), &o, s, &Sh)

@@ -43,14 +43,15 @@ SCENARIOS = [
 
 @pytest.mark.parametrize("name,copts", SCENARIOS)
 def test_native_gmres_matches_the_mirror(hs, name, copts):
-    """`hs_gmres_*` vs the torch mirror (gmres.py) on the scenario of test/rungmres.jl:32-48: exact and compressed preconditioners and no
+    """`hs_gmres_*` (the package's `gmres`) vs the torch mirror (tests/gmres_mirror.py) on the scenario of test/rungmres.jl:32-48: exact and compressed preconditioners and no
     preconditioner at all -- same iteration counts, same residual histories to rounding, same solution."""
+    from gmres_mirror import gmres_mirror
     from hierarchicalsolvers_jl_amd.gmres import gmres_native
 
     P = prepare(hs, name, rhs="randn") if isinstance(name, str) else prepare(hs, name[0], rhs="randn", **name[1])
     for label, F in (("exact", hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0)), ("compressed", hs.factor(P["A"], P["nd"], P["nd_loc"], **copts)), ("none", None)):
         kw = dict(Pr=F, reltol=1e-9, restart=30, log=True, maxiter=30 if F is not None else 45)
-        x1, c1 = hs.gmres(P["A"], P["b"], **kw)
+        x1, c1 = gmres_mirror(P["A"], P["b"], **kw)
         x2, c2 = gmres_native(P["A"], P["b"], **kw)
         print(name if isinstance(name, str) else name[0], label, "iterations: mirror", c1["iters"], "native", c2["iters"])
         assert c2["iters"] == c1["iters"] and c2["isconverged"] == c1["isconverged"], (label, c1["iters"], c2["iters"])
@@ -71,7 +72,9 @@ def test_native_gmres_arguments(hs):
 
     x0 = spla.splu(P["A"]).solve(P["b"]) * (1 + 1e-3)
     x, c = gmres_native(P["A"], P["b"], Pr=F, reltol=1e-6, restart=30, maxiter=10, log=True, x0=x0)
-    xm, cm = hs.gmres(P["A"], P["b"], Pr=F, reltol=1e-6, restart=30, maxiter=10, log=True, x0=x0)
+    from gmres_mirror import gmres_mirror
+
+    xm, cm = gmres_mirror(P["A"], P["b"], Pr=F, reltol=1e-6, restart=30, maxiter=10, log=True, x0=x0)
     assert c["iters"] == cm["iters"] and c["isconverged"] and relerr(x, xm) < 1e-8
     # b = 0: nothing to do
     x, c = gmres_native(P["A"], 0 * P["b"], Pr=F, reltol=1e-9, restart=30, maxiter=10, log=True)
