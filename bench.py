@@ -281,7 +281,7 @@ def main():
     is_c = np.iscomplexobj(Ap.data)
 
     fopts = dict(swlevel=args.swlevel, swsize=args.swsize, atol=args.tol, rtol=args.tol, split_size=args.split, hss_min=args.hss_min, hss_dexp=args.hss_dexp, mf=args.mf, leafsize=args.leafsize) if args.swlevel != 0 else dict(swlevel=0)
-    libcomm, dist_note, p2p_gbps = None, None, 0.0
+    libcomm, dist_note, p2p_gbps, p2p_all = None, None, 0.0, None
     if world > 1 and args.dist_top != 0 and args.swlevel == 0:
         # the library's own communicator (RCCL over xGMI under the nccl process group): used only if its ring self-test passes on EVERY rank
         # AND moves at least --dist-min-gbps per link (a fan-out slower than that would cost more than the idle ranks gain)
@@ -294,6 +294,9 @@ def main():
             ok, dist_note = 0, f"rank {rank}: {e!r}"
         on_dev = torch.distributed.get_backend() == "nccl"
         flag = torch.tensor([float(ok), bw], dtype=torch.float64, device=dev if on_dev else "cpu")
+        bw_all = [torch.zeros(1, dtype=torch.float64, device=flag.device) for _ in range(world)]
+        torch.distributed.all_gather(bw_all, flag[1:2].clone())
+        p2p_all = [float(t.item()) for t in bw_all]  # every rank's measured rate: a slow link shows up by its rank
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         p2p_gbps = float(flag[1].item())
         if int(flag[0].item()) == 1 and (p2p_gbps >= args.dist_min_gbps or libcomm.kind() == "host" or args.dist_top == 1):
@@ -342,6 +345,16 @@ def main():
         dt = float(tt.item())
     per_step = dt / max(args.steps, 1)
     st = S.stats()
+    # N > 1, host-driven joins: one more, INSTRUMENTED factorization (the host waits for the device after every stage; not part of `value`):
+    # what each rank spent computing, and sending / receiving -- which includes waiting for the peer -- so a first run on real links is diagnosable
+    rank_times = None
+    if world > 1 and not fopts.get("dist_top"):
+        tr = []
+        S.numeric(trace=tr)
+        mine = {"rank": rank, "compute_s": sum(t for w, t in tr if w.startswith("level")), "transfer_and_wait_s": sum(t for w, t in tr if w.startswith(("send", "recv"))),
+                "stages": [(w, round(t, 6)) for w, t in tr], "hss_bytes_moved": getattr(S.backend, "hss_bytes_moved", 0)}
+        rank_times = [None] * world
+        torch.distributed.all_gather_object(rank_times, mine)
     # ldiv! alone (part of every timed step; timed separately here for the HBM roofline of the solve kernels)
     t_ldiv = 0.0
     if world == 1:
@@ -468,6 +481,9 @@ def main():
             out["dist_top_note"] = dist_note
         if world > 1 and args.dist_top != 0 and args.swlevel == 0:
             out["comm_p2p_GBps"] = p2p_gbps  # measured through the library's communicator before the run (slowest rank)
+            out["comm_p2p_GBps_per_rank"] = p2p_all
+        if rank_times:
+            out["rank_times"] = rank_times
         if flops:
             out["factor_tflops_minimal_count"] = flops / st["t_total"] / 1e12
         if world == 1 and t_ldiv > 0 and st["bytes_solve"] > 0:

@@ -83,7 +83,7 @@ EXPORTS = [
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_expand", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_trim", "hs_hss_free", "hs_node_schur_hss",
     "hs_hss_offdiag", "hs_hss_bytes", "hs_hss_prune_leaves", "hs_hss_compatible", "hs_hss_depth", "hs_hss_compress_blockop_d", "hs_hss_compress_blockop_z", "hs_hss_blockop_apply",
     "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_mfma_f64_peak_random", "hsk_bisect_perm",
-    "hs_probs_stats_mode", "hs_probs_stats", "hs_trim",
+    "hs_probs_stats_mode", "hs_probs_stats", "hs_trim", "hs_stream_order",
 ]
 
 _lib = None
@@ -300,6 +300,8 @@ def lib():
     L.hs_hss_free.restype = None
     L.hsk_bisect_perm.argtypes = [i64, p_i64, p_i64, i64, p_i64, p_i64]
     L.hsk_bisect_perm.restype = C.c_int
+    L.hs_stream_order.argtypes = [vp, vp, C.c_int]
+    L.hs_stream_order.restype = C.c_int
     L.hs_trim.argtypes = []
     L.hs_trim.restype = i64
     L.hs_probs_stats_mode.argtypes = [C.c_int]

@@ -1604,6 +1604,17 @@ extern "C" int hs_exchange_info(const hs_handle* h, int64_t k, int64_t* out6) {
            const Exchange& e = h->exchanges[k]; out6[0] = e.node; out6[1] = e.level; out6[2] = e.src; out6[3] = e.dst; out6[4] = e.nb;
            out6[5] = e.nelems);
 }
+// Stream ordering between the library's stream and the host layer's (the communicator's) WITHOUT blocking the host: direction 0 = `other`
+// waits for everything the library has enqueued so far (before a send reads a Schur buffer), 1 = the library's stream waits for everything
+// enqueued on `other` so far (after a receive wrote one).  Round 2's host layer bracketed every transfer with device-wide synchronisations.
+extern "C" int hs_stream_order(hs_handle* h, void* other, int direction) {
+  HS_GUARD(check_device_handle(h); hipStream_t o = (hipStream_t)other; hipEvent_t e = nullptr;
+           HS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+           hipError_t st = hipEventRecord(e, direction == 0 ? h->stream : o);
+           if (st == hipSuccess) st = hipStreamWaitEvent(direction == 0 ? o : h->stream, e, 0);
+           (void)hipEventDestroy(e);  // (the runtime keeps the event alive until the wait has been satisfied)
+           if (st != hipSuccess) HS_FAIL(HS_ERR_DEVICE, 0, "hs_stream_order: %s", hipGetErrorString(st)));
+}
 extern "C" int64_t hs_exchange_kind(const hs_handle* h, int64_t k) {
   if (!h || k < 0 || k >= (int64_t)h->exchanges.size()) return -1;
   return h->exchanges[(size_t)k].hss;

@@ -220,14 +220,32 @@ def run_solve_dist(backend, plan, rank, comm, b):
     return b
 
 
-def run_numeric(backend, plan, rank, comm):
+def run_numeric(backend, plan, rank, comm, trace=None):
     """Numeric factorization: rank-local subtrees, then the fronts above the cut level by level,
-    receiving the remote child's Schur complement before each join."""
+    receiving the remote child's Schur complement before each join.
+
+    ``trace``: a list to which an INSTRUMENTED run appends ``(what, seconds)`` pairs -- the host waits for the device after every stage
+    (``backend.host_sync``), so the pairs are this rank's compute ("levels ..."), transfer ("send" / "recv": includes waiting for the
+    peer) and nothing else; a normal run (``trace=None``) never blocks the host."""
+    import time as _time
+
+    t_last = [_time.perf_counter()]
+
+    def lap(what):
+        if trace is None:
+            return
+        backend.host_sync()
+        now = _time.perf_counter()
+        trace.append((what, now - t_last[0]))
+        t_last[0] = now
+
     if plan.nranks > 1:
         backend.comm_sync()  # a send of the previous factorization may still read a Schur buffer this one overwrites
     backend.numeric_begin()
     L, cut = plan.nlevels, plan.cut_level
+    lap("begin")
     backend.numeric_levels(L, cut)
+    lap(f"levels {L}..{cut} (rank-local subtree)")
     for lv in range(cut - 1, 0, -1):
         for e in plan.at_child_level(lv + 1):
             if e.get("hss"):
@@ -248,17 +266,23 @@ def run_numeric(backend, plan, rank, comm):
                     backend.comm_sync()
                     backend.schur_hss_unpack(e["node"], buf)
                     backend.note_transfer(buf.numel())
+                if rank in (e["src"], e["dst"]):
+                    lap(("send" if e["src"] == rank else "recv") + f" HSS generators of node {e['node']} ({buf.numel()} bytes)")
                 continue
             if e["src"] == rank:
                 backend.sync()
                 comm.send(backend.schur_tensor(e["node"]), e["dst"])
                 backend.comm_sync()  # the communicator's stream is unknown to the library: the buffer is free again after this
+                lap(f"send dense S of node {e['node']} ({e['nelems']} elements)")
             elif e["dst"] == rank:
                 comm.recv(backend.schur_tensor(e["node"]), e["src"])
                 backend.comm_sync()
+                lap(f"recv dense S of node {e['node']} ({e['nelems']} elements)")
         backend.numeric_levels(lv, lv)
+        lap(f"level {lv}")
     backend.numeric_levels(0, 0)  # pseudo-root (root with a boundary), owned by rank 0
     backend.numeric_end()
+    lap("end")
 
 
 def run_solve(backend, plan, rank, comm, b):
@@ -434,11 +458,17 @@ class HipBackend:
         return dict(zip(keys, (int(v) for v in out)))
 
     def sync(self):
-        """Library stream -> host: data the library produced is complete before the communicator reads it."""
-        self.torch.cuda.synchronize(self.device)
+        """Library stream -> communicator: the stream the communicator works on (torch's current one) waits for everything the library has
+        enqueued, so a send reads complete data.  An event, not a host synchronisation (round 2 blocked the host on the whole device here)."""
+        _lib.check(self.L.hs_stream_order(self._h, self._stream(), 0))
 
     def comm_sync(self):
-        """Communicator -> host: received data is complete before the library's stream reads it."""
+        """Communicator -> library: the library's stream waits for what the communicator enqueued (a receive into a Schur / boundary buffer,
+        or a send still reading one that the next factorization overwrites)."""
+        _lib.check(self.L.hs_stream_order(self._h, self._stream(), 1))
+
+    def host_sync(self):
+        """Block the host until the device is idle (instrumented runs only: `run_numeric(..., trace=[])`)."""
         self.torch.cuda.synchronize(self.device)
 
     # -- solve ------------------------------------------------------------------------------------------------
@@ -497,13 +527,13 @@ class StagedSolver:
         # communicator); host_solve = True drives the same sweeps level by level from here (run_solve_dist, torch.distributed)
         self.host_solve = False
 
-    def numeric(self, values=None):
+    def numeric(self, values=None, trace=None):
         if values is not None:
             self.backend.set_values(values)
         if self.backend.dist_top:
             run_numeric_dist(self.backend)
         else:
-            run_numeric(self.backend, self.plan, self.rank, self.comm)
+            run_numeric(self.backend, self.plan, self.rank, self.comm, trace)
 
     def solve(self, b):
         """In place on a device tensor ``b`` of length n (every rank passes the same right-hand side)."""

@@ -169,6 +169,10 @@ int64_t hs_num_exchanges(const hs_handle* F);
  * node's Schur complement goes src -> dst before dst eliminates node's parent; in ldiv! the vector b[bnd(node)]
  * goes src -> dst in the forward sweep and dst -> src in the backward sweep. */
 int hs_exchange_info(const hs_handle* F, int64_t k, int64_t* out6);
+/* Order the library's stream against a stream of the host layer without blocking the host: direction 0 = `other_stream` waits for all work
+ * the library has enqueued (call before a send that reads a Schur / boundary buffer), 1 = the library's stream waits for all work enqueued on
+ * `other_stream` (call after a receive into such a buffer).  NULL = the legacy default stream. */
+int hs_stream_order(hs_handle* F, void* other_stream, int direction);
 /* 0: exchange k moves a dense Schur complement (hs_set_schur_buffer); 1: it moves an HSS matrix packed into one buffer whose size is known
  * only after the sender compressed it (hs_options.mf with nranks > 1: src calls hs_schur_pack_size + hs_schur_pack after the node's level,
  * ships the byte count and the buffer, dst calls hs_schur_unpack before the parent's level).  This is the reference's data flow over ranks:

@@ -17,6 +17,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _few_blas_threads_per_rank(monkeypatch):
+    """2-8 rank processes share the 8 cores of the CI container: one or two BLAS threads each (spawned children inherit the environment;
+    without this every rank starts 8 OpenBLAS / OpenMP threads and the world-8 cases take minutes)."""
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        monkeypatch.setenv(k, "1")
+
+
 def build_plan(hs, nd, nranks):
     """Independent restatement of the ownership rule (SURVEY.md 8(e)): cut at level p+1, 2^p = nranks;
     a front above the cut belongs to the first rank of its group."""
@@ -114,6 +122,9 @@ class OracleBackend:
         pass
 
     def comm_sync(self):
+        pass
+
+    def host_sync(self):
         pass
 
     # -- solve -----------------------------------------------------------------------------------------------
@@ -341,7 +352,7 @@ def _worker_dist(rank, world, port, name, q):
 
 
 @pytest.mark.parametrize("world,name", [(2, ((17, 13), "poisson", 12)), (4, ((17, 13), "poisson", 12)), (2, ((8, 8, 6), "helmholtz", 30)),
-                                        (4, ((8, 8, 6), "helmholtz", 30)), (8, ((33, 29), "poisson", 12))])
+                                        (4, ((8, 8, 6), "helmholtz", 30)), (8, ((33, 29), "poisson", 12)), (8, ((12, 10, 10), "helmholtz", 30))])
 def test_group_fronts_over_gloo(world, name):
     """dist_top: replicated fronts above the cut, pairwise swaps at the joins, no communication in the backward sweep."""
     import torch.multiprocessing as mp
