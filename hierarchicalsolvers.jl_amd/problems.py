@@ -213,6 +213,11 @@ NAMED = {
     "helmholtz3d_96": ((96, 96, 96), "helmholtz", 4096),
     "helmholtz3d_112": ((112, 112, 112), "helmholtz", 4096),  # largest complex 3-D problem whose dense factors fit one MI355X (163 GiB)
     "helmholtz3d_128": ((128, 128, 128), "helmholtz", 4096),  # 278 GiB of dense complex factors: needs >= 2 GPUs
+    # the 8-GPU compressed configurations (hs_options.mf over ranks; tools/size_model.py: per-rank bytes with the rank constant measured on
+    # Helmholtz 112^3 at 1e-4): leaves of 1,024 DOFs -- with 4,096 the dense leaf blocks alone are 137 GiB per rank at 256^3
+    "helmholtz3d_192": ((192, 192, 192), "helmholtz", 1024),  # every mf flow fits 8 x 288 GB (mf = 2: 121 GiB on the busiest rank)
+    "helmholtz3d_224": ((224, 224, 224), "helmholtz", 1024),  # mf = 2 only (201 GiB on the busiest rank)
+    "helmholtz3d_256": ((256, 256, 256), "helmholtz", 1024),  # BASELINE.json config 5: modelled at 313 GiB per rank with mf = 2 -- does NOT fit yet
 }
 
 

@@ -237,3 +237,35 @@ def test_plan_rejects_fronts_of_a_level_that_share_a_dof(hs):
     yc = tree["bnd_idx"][tree["bnd_ptr"][c]]
     with pytest.raises(hs.DimensionMismatch, match="listed twice"):
         hs.dist.plan_only(Ap, with_extra_bnd(c, yc), None)
+
+
+def test_size_model_restates_the_tree(hs):
+    """tools/size_model.py derives every front's (ni, nb) from the boxes alone (no index lists: 256^3 in seconds) -- the same numbers as the real
+    geometric nested dissection, in post-order; and its exact part (dense factor bytes) equals hs_plan's."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("size_model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "size_model.py"))
+    sm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sm)
+    for shape, nmax in (((12, 12, 12), 64), ((16, 16, 16), 128), ((9, 14, 11), 40)):
+        nd = hs.problems.grid_nested_dissection(shape, nmax)
+        real = [(len(x.int), len(x.bnd)) for x in hs.postorder_nodes(nd)]
+        model = [(x["ni"], x["nb"]) for x in sm.tree_sizes(shape, nmax)]
+        assert real == model, (shape, nmax)
+    # the dense bytes of the model = the library's own plan (one rank, exact)
+    from helpers import prepare
+
+    P = prepare(hs, (16, 16, 16), kind="poisson", nmax=128)
+    h = hs.dist.plan_only(P["A"], P["nd"], P["nd_loc"], rank=0, nranks=1)
+    try:
+        import ctypes as C
+
+        st = hs._lib.hs_stats()
+        hs._lib.check(hs._lib.lib().hs_get_stats(h, C.byref(st)))
+        plan_bytes = st.bytes_factors
+    finally:
+        hs._lib.lib().hs_free(h)
+    nodes = sm.tree_sizes(16, 128)
+    model_bytes = sum(sm.dense_front_elems(x["ni"], x["nb"]) for x in nodes) * 8
+    assert abs(model_bytes - plan_bytes) <= 0.02 * plan_bytes, (model_bytes, plan_bytes)  # (the plan pads leading dimensions and blocks of 32)
