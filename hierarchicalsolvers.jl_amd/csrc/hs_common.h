@@ -196,6 +196,8 @@ void launch_panel_l21(const NodeDesc<T>* dnodes, int nbatch, int pb, int maxrows
 template <class T>
 bool launch_trsm_small(const NodeDesc<T>* dnodes, int nbatch, int mat, int r0, int rows, int c0, int c1, int maxcols, hipStream_t s);  // 64 / 128 rows in one launch
 template <class T>
+bool launch_group256(const NodeDesc<T>* dnodes, int nbatch, int grp, hipStream_t s);  // the panel chain of the 256 x 256 diagonal block of group `grp` in one launch (Float64; false: not available)
+template <class T>
 void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1, int k0, int k1, int maxcols, hipStream_t s);
 
 template <class T>

@@ -257,9 +257,16 @@ struct Sched {
   void lu_rec(int c0, int c1) {
     if (c0 >= maxni) return;
     if (c1 - c0 == 256 && diag_first()) {
-      rlim = c0 + 256;
-      lu_rec_inner(c0, c1);
-      rlim = HS_BIG;
+      hipEvent_t eg = pf->begin(s);
+      if (launch_group256<T>(dn, nbatch, c0 / 256, s)) {  // the whole chain of the diagonal block in one launch (kernels_panel.hip)
+        pf->end(eg, HS_CAT_PANEL, s);
+        dbg("group256", c0);
+      } else {
+        if (eg) (void)hipEventDestroy(eg);
+        rlim = c0 + 256;
+        lu_rec_inner(c0, c1);
+        rlim = HS_BIG;
+      }
       launch_inv256<T>(sn, nbatch, maxni, s, c0 / 256);
       const int r0 = c0 + 256;
       if (r0 < maxm) {

@@ -689,6 +689,291 @@ __global__ __launch_bounds__(256) void panel_pivot_opt_kernel(const NodeDesc<dou
 }
 
 // ------------------------------------------------------------------------------------------------
+// group256: the WHOLE panel chain of a 256-column group on its 256 x 256 diagonal block in ONE launch (Float64, optimistic pivoting).
+// Sched::lu_rec (diagonal-block-first groups) ran it as 28 dependent launches -- 8 x (pivot, L21), the swaps, the 64 / 128-row solves and the
+// K <= 128 updates of the recursion, every one a single workgroup -- which next to a running GEMM cost 1.9 ms per group (tools/factor_trace.sh:
+// each launch waits for a slot, runs 2x slower beside MFMA waves, and leaves the chip a launch gap): the 32,768 root of Poisson 128^3 spent
+// 463 ms on 370 ms of GEMM.  Here one workgroup walks the eight 32-column panels of the block right-looking:
+//   wave 0         LU of the 32 x 32 diagonal block with the pivot search inside (rows in registers, lane = row: panel_pivot_opt's elimination)
+//   waves 1, 2     inv(L11), inv(U11) (registers -> LDS and the stored inverse blocks); wave 0 meanwhile: ipiv, rperm, the L\U block
+//   all threads    one OTHER column of the block each: its 32 rows gathered in pivot order (the swaps), and right of the panel
+//                  U12 = inv(L11) * (P A12), kept in LDS
+//   all threads    one row BELOW the panel each: L21 = A21 * inv(U11) (growth bound checked), then the rank-32 update of that row over all
+//                  trailing columns of the block from U12 in LDS
+// Four barriers and ~20 us per panel, nothing but this workgroup's own L2-resident block touched; 77 KB of LDS (fits next to one GEMM
+// workgroup).  The rows below the block follow as before: inv256 of the group, then L_below = A_below * inv(U_group) (GemmOp::ainv 7, 8).
+// ------------------------------------------------------------------------------------------------
+#define HS_G256_LDU 34  // U12 image: [column][k], 32 + 2 padding (16-byte reads of a k pair, rows of consecutive columns on different banks)
+__global__ __launch_bounds__(256) void group256_kernel(const NodeDesc<double>* __restrict__ nodes, int grp) {
+  __builtin_amdgcn_s_setprio(3);
+  const NodeDesc<double> nd = nodes[blockIdx.y];
+  const int g0 = grp * 256;
+  if (g0 >= nd.ni) return;
+  const int wl = min(256, nd.ni - g0);        // order of the diagonal block
+  const int g1 = g0 + wl;
+  const int rend = min(nd.m, g0 + 256);       // rows this kernel owns: the block's, and under a PARTIAL last group the boundary rows up to g0 + 256
+                                              // (the products of the rows below start at g0 + 256, Sched::lu_rec)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const size_t ld = nd.ldl;
+  double* const LF = nd.LF;
+  extern __shared__ __attribute__((aligned(16))) double g256_smem[];
+  double* s_u = g256_smem;                                   // [224][HS_G256_LDU]
+  double (*s_a)[HS_PB + 1] = reinterpret_cast<double (*)[HS_PB + 1]>(s_u + 224 * HS_G256_LDU);  // L\U of the diagonal block, pivoted order
+  double (*s_il)[HS_PB + 1] = s_a + HS_PB;
+  double (*s_iu)[HS_PB + 1] = s_il + HS_PB;
+  int* s_pl = reinterpret_cast<int*>(s_iu + HS_PB);          // row (front position) that ends at top position c+k
+  int* s_piv = s_pl + HS_PB;
+  int* s_where = s_piv + HS_PB;
+  int* s_what = s_where + HS_PB;
+  int* s_r = s_what + HS_PB;
+
+  for (int c = g0; c < g1; c += HS_PB) {
+    const int w = min(HS_PB, g1 - c);
+    const int pb = c / HS_PB;
+    // ---- 1. the diagonal block: one elimination with the pivot search inside (wave 0); rperm of its rows (wave 3) ---------------------------
+    if (wave == 0) {
+      const int i = lane & 31;
+      bool alive = lane < w;
+      int pos = (lane >= w && lane < HS_PB) ? lane : -1;  // padding rows keep their place
+      double x[HS_PB];
+#pragma clang loop unroll(full)
+      for (int j = 0; j < HS_PB; ++j) x[j] = (lane < w && j < w) ? gld(LF + (size_t)(c + i) + (size_t)(c + j) * ld) : ((lane < HS_PB && i == j) ? 1.0 : 0.0);
+      bool bad = false;
+#pragma clang loop unroll(full)
+      for (int k = 0; k < HS_PB; ++k) {
+        if (k < w) {  // wave-uniform
+          unsigned long long key = 0;
+          if (alive) key = ((unsigned long long)__double_as_longlong(fabs(x[k])) & ~0xffull) | (unsigned long long)(255 - lane);
+          const unsigned long long best = wave_max_u64(key);
+          int win;
+          double rp;
+          if ((best >> 8) != 0) {
+            win = 255 - (int)(best & 0xff);
+            rp = 1.0 / lane_bcast(x[k], win);
+          } else {  // the column is zero on every row still in play: singular on its own rows -> the level is redone with the tournament
+            bad = true;
+            const unsigned long long m = __ballot(alive);
+            win = m ? (__ffsll((long long)m) - 1) : 0;
+            rp = 0.0;
+          }
+          win = __builtin_amdgcn_readfirstlane(win);
+          if (lane == 0) s_pl[k] = c + win;
+          double l = 0.0;
+          if (alive && lane != win) {
+            l = x[k] * rp;
+            x[k] = l;
+          }
+          if (lane == win) {
+            alive = false;
+            pos = k;
+          }
+#pragma clang loop unroll(full)
+          for (int j = 0; j < HS_PB; ++j)
+            if (j > k) x[j] = fma(-l, lane_bcast(x[j], win), x[j]);
+        } else if (lane == 0) {
+          s_pl[k] = c + k;
+        }
+      }
+      if (bad && lane == 0 && nd.growth) *nd.growth = 1;
+      if (pos >= 0) {
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j) s_a[pos][j] = x[j];
+      }
+    } else if (wave == 3) {
+      if (lane < HS_PB) s_r[lane] = (lane < w) ? nd.rperm[c + lane] : 0;
+    }
+    __syncthreads();
+    // ---- 2. inverses of L11, U11 (waves 1, 2); swaps for laswp on the columns outside the group, rperm, the L\U block (wave 0) --------------
+    if (wave == 0) {
+      if (lane == 0) {
+        for (int k = 0; k < HS_PB; ++k) {
+          s_where[k] = c + k;
+          s_what[k] = c + k;
+        }
+        for (int k = 0; k < w; ++k) {
+          const int r = s_pl[k];
+          const int target = c + k;
+          const int p = s_where[r - c];
+          s_piv[k] = p;
+          if (p != target) {
+            const int q = s_what[k];
+            s_what[k] = r;
+            s_what[p - c] = q;
+            s_where[r - c] = target;
+            s_where[q - c] = p;
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): lane 0's LDS writes are visible to the wave's later reads
+      if (lane < w) {
+        nd.ipiv[c + lane] = s_piv[lane];
+        nd.rperm[c + lane] = s_r[s_pl[lane] - c];
+      }
+      const int i = lane & 31, jh = lane >> 5;
+#pragma clang loop unroll(full)
+      for (int jj = 0; jj < HS_PB / 2; ++jj) {
+        const int j = 2 * jj + jh;
+        if (i < w && j < w) gst(LF + (size_t)(c + i) + (size_t)(c + j) * ld, s_a[i][j]);
+      }
+    } else if (wave == 1) {
+      if (lane < HS_PB) {  // inv(L): the row operations that reduce L to I applied to I; lane i owns row i
+        const int i = lane;
+        double lr[HS_PB], il[HS_PB];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j) {
+          lr[j] = s_a[i][j];
+          il[j] = (i == j) ? 1.0 : 0.0;
+        }
+#pragma clang loop unroll(full)
+        for (int k = 0; k < HS_PB - 1; ++k) {
+          const double l = (i > k) ? lr[k] : 0.0;
+#pragma clang loop unroll(full)
+          for (int j = 0; j < HS_PB; ++j)
+            if (j <= k) il[j] = fma(-l, lane_bcast(il[j], k), il[j]);
+        }
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j) {
+          gst(nd.invL + (size_t)pb * HS_PB * HS_PB + i + j * HS_PB, il[j]);
+          s_il[i][j] = il[j];
+        }
+      }
+    } else if (wave == 2) {
+      if (lane < HS_PB) {  // inv(U) by back substitution in rank-1 form (a zero pivot counts as 1: the front is already flagged)
+        const int i = lane;
+        double ar[HS_PB], iu[HS_PB];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j) {
+          ar[j] = s_a[i][j];
+          iu[j] = (i == j) ? 1.0 : 0.0;
+        }
+#pragma clang loop unroll(full)
+        for (int p = HS_PB - 1; p >= 0; --p) {
+          double d = lane_bcast(ar[p], p);
+          if (d == 0.0) d = 1.0;
+          const double rd = 1.0 / d;
+          const double u = (i < p) ? ar[p] : 0.0;
+#pragma clang loop unroll(full)
+          for (int j = 0; j < HS_PB; ++j) {
+            if (j >= p) {
+              if (i == p) iu[j] = iu[j] * rd;
+              const double rowp = lane_bcast(iu[j], p);
+              iu[j] = fma(-u, rowp, iu[j]);
+            }
+          }
+        }
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j) {
+          gst(nd.invU + (size_t)pb * HS_PB * HS_PB + i + j * HS_PB, iu[j]);
+          s_iu[i][j] = iu[j];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 3. every other column of the block: its 32 rows in pivot order; right of the panel U12 = inv(L11) * (P A12), kept in LDS ---------------
+    {
+      const int nother = wl - w;  // columns of the block outside the panel
+      if (t < nother) {
+        const int col = (g0 + t < c) ? g0 + t : g0 + t + w;  // left of the panel, then right of it
+        double* cp = LF + (size_t)col * ld;
+        double xp[HS_PB];
+#pragma clang loop unroll(full)
+        for (int k = 0; k < HS_PB; ++k) xp[k] = (k < w) ? gld(cp + s_pl[k]) : 0.0;
+        if (col < c) {
+#pragma clang loop unroll(full)
+          for (int k = 0; k < HS_PB; ++k)
+            if (k < w) gst(cp + c + k, xp[k]);
+        } else {
+          const int j = col - (c + w);
+          double* su = s_u + (size_t)j * HS_G256_LDU;
+#pragma clang loop unroll(full)
+          for (int i = 0; i < HS_PB; ++i) {
+            double u = 0.0;
+#pragma clang loop unroll(full)
+            for (int q = 0; q < HS_PB; ++q)
+              if (q <= i) u = fma(s_il[i][q], xp[q], u);
+            if (i < w) gst(cp + c + i, u);
+            su[i] = (i < w) ? u : 0.0;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 4. every row below the panel: L21 = A21 * inv(U11), then its rank-32 update over the trailing columns of the block -------------------
+    {
+      const int r = c + w + t;
+      if (r < rend) {
+        double* rp_ = LF + (size_t)r;
+        double a[HS_PB], l[HS_PB];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j) a[j] = (j < w) ? gld(rp_ + (size_t)(c + j) * ld) : 0.0;
+        bool big = false;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < HS_PB; ++j) {
+          double sacc = 0.0;
+#pragma clang loop unroll(full)
+          for (int i = 0; i < HS_PB; ++i)
+            if (i <= j) sacc = fma(a[i], s_iu[i][j], sacc);
+          l[j] = sacc;
+          if (!(fabs(sacc) <= HS_GROWTH_MAX)) big = true;  // NaN counts
+          if (j < w) gst(rp_ + (size_t)(c + j) * ld, sacc);
+        }
+        if (big && r < nd.pivrows && nd.growth) *nd.growth = 1;
+        const int ntr = g1 - (c + w);
+        double* tp = rp_ + (size_t)(c + w) * ld;
+        // eight columns per pass, the next eight loaded while these are updated: one global round trip per 256 FMAs, eight independent FMA
+        // chains (a lone wave per SIMD hides neither the ~1 us of an L2 load nor the FMA latency by itself)
+        constexpr int CH = 8;
+        double v[CH], vn[CH];
+#pragma clang loop unroll(full)
+        for (int q = 0; q < CH; ++q) v[q] = gld(tp + (size_t)min(q, max(ntr - 1, 0)) * ld);  // (branch-free: past the end the last column is re-read, never stored)
+        for (int j = 0; j < ntr; j += CH) {
+#pragma clang loop unroll(full)
+          for (int q = 0; q < CH; ++q) vn[q] = gld(tp + (size_t)min(j + CH + q, ntr - 1) * ld);
+          const double* ub = s_u + (size_t)j * HS_G256_LDU;  // (columns past ntr read LDS that belongs to this workgroup and are never stored)
+#pragma clang loop unroll(full)
+          for (int k = 0; k < HS_PB; k += 2) {
+#pragma clang loop unroll(full)
+            for (int q = 0; q < CH; ++q) {
+              const hs_d2u uu = *reinterpret_cast<const hs_d2u*>(ub + q * HS_G256_LDU + k);
+              v[q] = fma(-l[k], uu.x, v[q]);
+              v[q] = fma(-l[k + 1], uu.y, v[q]);
+            }
+          }
+#pragma clang loop unroll(full)
+          for (int q = 0; q < CH; ++q) {
+            if (j + q < ntr) gst(tp + (size_t)(j + q) * ld, v[q]);
+            v[q] = vn[q];
+          }
+        }
+      }
+    }
+    __syncthreads();  // the next diagonal block and s_u are final / free
+  }
+}
+
+template <class T>
+bool launch_group256(const NodeDesc<T>* dnodes, int nbatch, int grp, hipStream_t s) {
+  if constexpr (sizeof(T) != 8) {
+    return false;  // ComplexF64 keeps the launch chain (the register eliminations are 4x the code)
+  } else {
+    // OFF by default (HS_GROUP_FUSED=1 turns it on): measured on MI355X it is correct (all parity tests) but no faster than the launch chain it
+    // replaces -- 489 us per group ALONE on the device (rocprofv3, 2-D fronts of 258), because the eight 32 x 32 eliminations are serial single-wave
+    // work of ~30 us each (v_readlane broadcasts), and 3.53 s instead of 3.35 s on Poisson 128^3: with 256 VGPRs + 66 AGPRs per lane its four waves
+    // need BOTH GEMM workgroups of a CU to retire before they can be placed, where the small chain kernels slip in after one.
+    static const bool on = getenv("HS_GROUP_FUSED") && getenv("HS_GROUP_FUSED")[0] == '1';
+    if (!on || nbatch <= 0) return false;
+    constexpr int lds = (224 * HS_G256_LDU + 3 * HS_PB * (HS_PB + 1)) * (int)sizeof(double) + 5 * HS_PB * (int)sizeof(int);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)group256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL(group256_kernel, dim3(1, nbatch), dim3(256), lds, s, dnodes, grp);
+    return true;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // laswp: apply swaps ipiv[k0:k1) to columns [c0, c1) of LF or UR (one column per thread)
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -937,6 +1222,7 @@ void launch_laswp(const NodeDesc<T>* dnodes, int nbatch, int mat, int c0, int c1
   template void launch_panel_l21<T>(const NodeDesc<T>*, int, int, int, int, hipStream_t, int);               \
   template void launch_laswp<T>(const NodeDesc<T>*, int, int, int, int, int, int, int, hipStream_t);    \
   template bool launch_trsm_small<T>(const NodeDesc<T>*, int, int, int, int, int, int, int, hipStream_t); \
+  template bool launch_group256<T>(const NodeDesc<T>*, int, int, hipStream_t);                             \
 
 INST(double)
 INST(cplx)
