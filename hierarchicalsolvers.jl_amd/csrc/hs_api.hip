@@ -117,6 +117,13 @@ struct NodeH {
   bool dist = false;      // hs_options.dist_top: a front above the rank cut eliminated by its whole group (hs_dist.h); `mine` = member of the group
   int ldl = 0, ldu = 0, lds = 0;
   size_t off_LF = 0, off_UR = 0, off_SB = 0, off_inv = 0, off_inv256 = 0;        // element offsets
+  // A compressed front (low-rank L / R, hs_compress.h) needs its dense front [Aii; Abi | Aib] only WHILE its level is eliminated: afterwards the
+  // Gauss transforms live in the low-rank objects and only the LU of Aii is read again (ldiv!).  Such a front is assembled and eliminated in a
+  // per-level SCRATCH arena (off_LF / off_UR index hs_handle::d_cfs) and its LU is copied, compactly (leading dimension ni), into the factor
+  // arena at off_LFc: 2 ni nb elements per front less to keep (29 GiB of 153 at Poisson 128^3 with levels 2-4 compressed).
+  bool cfront = false;
+  size_t off_LFc = 0;
+  int ldc = 2;
   size_t off_fidx = 0, off_ipiv = 0, off_rperm = 0, off_cmap = 0, off_cand = 0;  // int offsets
   int ncand = 0;
   int batch_pos = -1;      // index inside its level's batch of owned fronts
@@ -168,6 +175,7 @@ struct LevelH {
   std::vector<int> mine;   // nodes this rank eliminates
   int maxni = 0, maxnb = 0, maxm = 0, maxnbc = 0;
   size_t lf_begin = 0, lf_end = 0;  // factor-arena range (elements) of this level's LF/UR
+  size_t cfs_end = 0;               // scratch-arena extent (elements) of this level's compressed fronts (NodeH::cfront)
   size_t sb_begin = 0, sb_end = 0;  // SB range (elements)
   size_t desc_off = 0;              // first NodeDesc / SolveNode of this level (owned fronts only)
   size_t sc_off = 0, sc_cnt = 0;    // ScatterDesc range
@@ -190,6 +198,8 @@ struct Exchange {
 
 struct hs_handle {
   size_t fac_bytes = 0, inv_bytes = 0, sb_bytes = 0;  // sizes d_fac / d_inv / d_sb were asked for (the arena cache parks them by size)
+  void* d_cfs = nullptr;                              // scratch arena of the compressed fronts (NodeH::cfront), one level at a time
+  size_t cfs_bytes = 0, cfs_elems = 0;
   bool is_complex = false;
   int64_t n = 0, nnz = 0;
   int nnodes = 0;  // tree nodes (+1 pseudo-node when the root keeps a boundary)
@@ -347,6 +357,7 @@ static void free_handle(hs_handle* h) {
   arena_give(h->d_fac, h->fac_bytes);
   arena_give(h->d_inv, h->inv_bytes);
   arena_give(h->d_sb, h->sb_bytes);
+  arena_give(h->d_cfs, h->cfs_bytes);
   void* ptrs[] = {h->d_int, h->d_tmpi, h->d_colptr, h->d_rowval, h->d_nz,
                   h->d_nodes, h->d_sc,  h->d_solve, h->d_w1,  h->d_w2,   h->d_part,   h->d_b,   h->d_owned,
                   h->d_rowptr, h->d_colind, h->d_tperm, h->d_nzr, h->d_lpos};
@@ -761,12 +772,14 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     // ---- HBM layout (owned fronts: LF/UR/inv; owned + ghost fronts: SB) ------------------------------
     size_t fac = 0, inv = 0, ints = h->fidx_host.size(), tmpi = 0;
     size_t sbpar[2] = {0, 0};
+    size_t cfs_max = 0;
     std::vector<size_t> sb_level_size(h->levels.size(), 0);
     long long woff = 0, poff = 0;
     size_t ndesc = 0;
     for (int lv = (int)h->levels.size() - 1; lv >= 0; --lv) {
       LevelH& L = h->levels[lv];
       L.lf_begin = fac;
+      size_t cfs_lv = 0;
       L.desc_off = ndesc;
       ndesc += L.mine.size();
       size_t sb = 0;
@@ -803,10 +816,22 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           }
           continue;
         }
-        x.off_LF = fac;
-        fac += rups((size_t)x.ldl * x.ni, 32);
-        x.off_UR = fac;
-        fac += rups((size_t)x.ldu * x.nb, 32);
+        static const bool cfront_on = !(getenv("HS_COMPACT_D") && getenv("HS_COMPACT_D")[0] == '0');
+        x.cfront = cfront_on && x.compressed && !x.hssd && !x.leaf && !x.dist && !split.active && x.nb > 0;
+        if (x.cfront) {
+          x.ldc = rup(std::max(x.ni, 1), 2);
+          x.off_LFc = fac;
+          fac += rups((size_t)x.ldc * x.ni, 32);
+          x.off_LF = cfs_lv;
+          cfs_lv += rups((size_t)x.ldl * x.ni, 32);
+          x.off_UR = cfs_lv;
+          cfs_lv += rups((size_t)x.ldu * x.nb, 32);
+        } else {
+          x.off_LF = fac;
+          fac += rups((size_t)x.ldl * x.ni, 32);
+          x.off_UR = fac;
+          fac += rups((size_t)x.ldu * x.nb, 32);
+        }
         int nblk = (x.ni + HS_PB - 1) / HS_PB;
         x.off_inv = inv;
         inv += (size_t)2 * nblk * HS_PB * HS_PB;
@@ -827,6 +852,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
         woff += x.ni;
       }
       L.lf_end = fac;
+      L.cfs_end = cfs_lv;
+      cfs_max = std::max(cfs_max, cfs_lv);
       sb_level_size[lv] = sb;
       if (!opts.keep_schur) sbpar[lv & 1] = std::max(sbpar[lv & 1], sb);
     }
@@ -853,6 +880,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
       ex.nelems = ex.hss ? 0 : (long long)N[ex.node].lds * N[ex.node].nb;
     }
     h->fac_elems = fac;
+    h->cfs_elems = cfs_max;
     h->inv_elems = inv;
     h->sb_elems = sb_total;
     h->int_elems = ints;
@@ -907,6 +935,7 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     HS_HIP(hipMemset(h->d_inv, 0, inv * sizeof(T)));  // identity padding / unwritten corners must read as zero
     lapa("memset of the inverse blocks");
     dmalloc_arena(&h->d_sb, &h->sb_bytes, sb_total * sizeof(T), "the Schur-complement scratch");
+    if (h->cfs_elems > 0) dmalloc_arena(&h->d_cfs, &h->cfs_bytes, h->cfs_elems * sizeof(T), "the scratch fronts of the compressed levels");
     lapa("hipMalloc of the Schur scratch");
     dmalloc((void**)&h->d_int, ints * sizeof(int), "index lists");
     const size_t tmpi_total = tmpi + 2 * (size_t)h->nnodes + 2 * (size_t)n;
@@ -1002,8 +1031,8 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
           NodeH& x = N[id];
           NodeDesc<T> d;
           memset(&d, 0, sizeof d);
-          d.LF = dfac + x.off_LF;
-          d.UR = dfac + x.off_UR;
+          d.LF = (x.cfront ? (T*)h->d_cfs : dfac) + x.off_LF;  // (the solve descriptor below points there too until the level is done: factor_compressed_level)
+          d.UR = (x.cfront ? (T*)h->d_cfs : dfac) + x.off_UR;
           d.SB = dsb + x.off_SB;
           int nblk = (x.ni + HS_PB - 1) / HS_PB;
           d.invL = dinv + x.off_inv;
@@ -1189,6 +1218,7 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     // zero-fill this level's fronts: LF/UR are contiguous per level; SB of the owned fronts only
     // (a ghost child's SB holds received data and must survive)
     if (L.lf_end > L.lf_begin) HS_HIP(hipMemsetAsync(dfac + L.lf_begin, 0, (L.lf_end - L.lf_begin) * sizeof(T), s));
+    if (L.cfs_end > 0) HS_HIP(hipMemsetAsync(h->d_cfs, 0, L.cfs_end * sizeof(T), s));  // the scratch fronts of this level's compressed fronts
     if (h->nranks == 1) {
       if (L.sb_end > L.sb_begin) HS_HIP(hipMemsetAsync(dsb + L.sb_begin, 0, (L.sb_end - L.sb_begin) * sizeof(T), s));
     } else {
@@ -1546,6 +1576,8 @@ static int factor_entry(int64_t n, const int64_t* colptr, const int64_t* rowval,
     if (!h->sb_kept) {  // one-shot path: the Schur scratch is not needed again
       arena_give(h->d_sb, h->sb_bytes);
       h->d_sb = nullptr;
+      arena_give(h->d_cfs, h->cfs_bytes);  // (the compact LUs of the compressed fronts live in the factor arena)
+      h->d_cfs = nullptr;
     }
     lap("free of the Schur scratch");
     *out = h;
@@ -1820,7 +1852,9 @@ static void export_block(const hs_handle* F, const NodeH& x, int which, T* out) 
   const T* base;
   int rows, cols, ld;
   switch (which) {
-    case HS_BLK_LU: base = (const T*)F->d_fac + x.off_LF; rows = x.ni; cols = x.ni; ld = x.ldl; break;
+    case HS_BLK_LU:
+      if (x.cfront) { base = (const T*)F->d_fac + x.off_LFc; rows = x.ni; cols = x.ni; ld = x.ldc; break; }
+      base = (const T*)F->d_fac + x.off_LF; rows = x.ni; cols = x.ni; ld = x.ldl; break;
     case HS_BLK_LBI: base = (const T*)F->d_fac + x.off_LF + x.ni; rows = x.nb; cols = x.ni; ld = x.ldl; break;
     case HS_BLK_UIB: base = (const T*)F->d_fac + x.off_UR; rows = x.ni; cols = x.nb; ld = x.ldu; break;
     case HS_BLK_S:

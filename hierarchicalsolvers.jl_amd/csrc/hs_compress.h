@@ -76,6 +76,21 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
   NodeDesc<T>* dd = (NodeDesc<T>*)h->d_cdesc;
   std::vector<NodeDesc<T>> hd(count), tmp(count);
   HS_HIP(hipMemcpy(hd.data(), dn, sizeof(NodeDesc<T>) * count, hipMemcpyDeviceToHost));
+  // fronts that live in the scratch arena (NodeH::cfront): while the level is eliminated their solve descriptors point at the scratch front
+  // too (lu_rec builds the 256 x 256 inverse blocks from it); at the end the LU moves to its compact place and the descriptors follow
+  std::vector<SolveNode<T>> hsn(count);
+  bool any_cfront = false;
+  for (int i = 0; i < count; ++i) any_cfront = any_cfront || h->nodes[ids[i]].cfront;
+  if (any_cfront) {
+    if (!h->d_cfs) HS_FAIL(HS_ERR_ARGUMENT, ids[0], "internal: the scratch arena of the compressed fronts was released (one-shot factorizations cannot be repeated)");
+    HS_HIP(hipMemcpy(hsn.data(), sn, sizeof(SolveNode<T>) * count, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; ++i) {
+      if (!h->nodes[ids[i]].cfront) continue;
+      hsn[i].LF = hd[i].LF;
+      hsn[i].ldl = hd[i].ldl;
+    }
+    HS_HIP(hipMemcpy((void*)sn, hsn.data(), sizeof(SolveNode<T>) * count, hipMemcpyHostToDevice));
+  }
   int maxni = 0, maxnb = 0;
   for (int i = 0; i < count; ++i) {
     maxni = std::max(maxni, hd[i].ni);
@@ -244,6 +259,17 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
       int e = rtrsm_upper_batch<T>(rj.data(), count, s, &dp);
       if (dp) tofree.push_back(dp);
       if (e != 0) HS_FAIL(HS_ERR_DEVICE, ids[0], "right triangular solves of level %d failed (HIP error %d)", h->nodes[ids[0]].level, e);
+    }
+    if (any_cfront) {  // the LU of Aii to its compact place in the factor arena; ldiv! reads it there
+      for (int i = 0; i < count; ++i) {
+        const NodeH& x = h->nodes[ids[i]];
+        if (!x.cfront || x.ni == 0) continue;
+        T* dst = (T*)h->d_fac + x.off_LFc;
+        HS_HIP(hipMemcpy2DAsync(dst, (size_t)x.ldc * sizeof(T), hd[i].LF, (size_t)hd[i].ldl * sizeof(T), (size_t)x.ni * sizeof(T), (size_t)x.ni, hipMemcpyDeviceToDevice, s));
+        hsn[i].LF = dst;
+        hsn[i].ldl = x.ldc;
+      }
+      HS_HIP(hipMemcpyAsync((void*)sn, hsn.data(), sizeof(SolveNode<T>) * count, hipMemcpyHostToDevice, s));  // (hsn outlives the synchronisation below)
     }
     HS_HIP(hipStreamSynchronize(s));
     lap("F: Z_L U^-1");
