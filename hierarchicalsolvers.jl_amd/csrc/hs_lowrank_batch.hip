@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <numeric>
+#include <cmath>
 #include <vector>
 
 #include "hs_sched.h"
@@ -24,6 +26,12 @@ __device__ inline uint64_t mix64(uint64_t x) {
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
+template <class T>
+__device__ inline T from_scale(double a);
+template <>
+__device__ inline double from_scale<double>(double a) { return a; }
+template <>
+__device__ inline cplx from_scale<cplx>(double a) { return {a, 0.0}; }
 __global__ __launch_bounds__(256) void randn_fill_kernel(double* out, size_t n, uint64_t seed) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -31,6 +39,50 @@ __global__ __launch_bounds__(256) void randn_fill_kernel(double* out, size_t n, 
   double u1 = ((a >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0, 1]
   double u2 = (b >> 11) * (1.0 / 9007199254740992.0);
   out[i] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sparse sign sketch Y = X * Omega for LARGE blocks (the Gauss transforms of a compressed front: X is nb x ni, 12,544 x 12,320 complex at
+// level 2 of Helmholtz 112^3): Omega is ni x k with HS_SKETCH_ZETA (8) nonzeros +-sqrt(k / zeta) per ROW -- every column of X is added, with a
+// random sign, into zeta of the k sketch columns (Clarkson-Woodruff / sparse Johnson-Lindenstrauss embeddings; Martinsson & Tropp 2020,
+// section 9.2: as good as a Gaussian test matrix for range finding from zeta ~ 8 on).  A Gaussian Omega costs 2 m n k flops in the MFMA GEMM --
+// 1.6e12 for that block, 110 of the 204 ms the level spends compressing Aib / Abi -- the sparse one reads X zeta times: m n zeta adds,
+// HBM / L2-bound (20 GB, ~5 ms).  Bucket of column j in repetition t: pi_t(j) mod k with pi_t(j) = (a_t j + b_t) mod n, gcd(a_t, n) = 1 (a
+// permutation of the columns, 2-universal); the kernel is gather-form -- one workgroup per (256 rows, sketch column c) walks
+// pi_t^-1(c), pi_t^-1(c + k), ... -- so it needs no atomics and is deterministic.  E |x Omega|^2 = k |x|^2 like the Gaussian sketch's.
+// ------------------------------------------------------------------------------------------------
+#define HS_SKETCH_ZETA 8
+template <class T>
+struct SparseSketchJob {
+  const T* X;
+  T* Y;
+  int ldx, ldy, rows, cols, k;
+  unsigned long long seed;
+  unsigned int ainv[HS_SKETCH_ZETA], b[HS_SKETCH_ZETA];
+  double scale;
+};
+template <class T>
+__global__ __launch_bounds__(256) void sparse_sketch_kernel(const SparseSketchJob<T>* __restrict__ jobs) {
+  const SparseSketchJob<T> J = jobs[blockIdx.z];
+  const int c = blockIdx.y;
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (c >= J.k || (int)blockIdx.x * 256 >= J.rows) return;  // workgroup-uniform
+  const bool live = row < J.rows;
+  const T* xr = J.X + (size_t)(live ? row : 0);
+  T acc = Scal<T>::zero();
+  const unsigned long long n = (unsigned long long)J.cols;
+#pragma unroll 1
+  for (int t = 0; t < HS_SKETCH_ZETA; ++t) {
+    const unsigned long long ai = J.ainv[t], bt = J.b[t];
+#pragma unroll 4
+    for (int p = c; p < J.cols; p += J.k) {  // positions c, c + k, ... of the permuted order: the columns of bucket c
+      const unsigned long long j = (ai * (((unsigned long long)p + n - bt) % n)) % n;   // pi_t^-1(p), uniform over the workgroup
+      const unsigned long long h = mix64(J.seed ^ ((unsigned long long)(t + 1) << 48) ^ j);
+      const T v = gld(xr + (size_t)j * J.ldx);
+      acc = (h & 1ull) ? acc + v : acc - v;
+    }
+  }
+  if (live) J.Y[(size_t)row + (size_t)c * J.ldy] = acc * from_scale<T>(J.scale);
 }
 
 template <class T>
@@ -98,11 +150,15 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
     std::vector<size_t> offOm(nj), offInv(nj), offInt(nj), offDg(nj);
     size_t nOm = 0, nInv = 0, nInt = 0, nDg = 0;
     int maxk = 0, maxrows = 0, maxcols = 0;
+    // large blocks take the sparse sign sketch (sparse_sketch_kernel above); HS_SKETCH=gauss keeps the Gaussian one everywhere (diagnostics)
+    static const bool sparse_on = !(getenv("HS_SKETCH") && getenv("HS_SKETCH")[0] == 'g');
+    std::vector<char> sparse(nj, 0);
     for (int a = 0; a < nj; ++a) {
       const LowRankJob<T>& J = jobs[todo[a]];
+      sparse[a] = sparse_on && (size_t)J.rows * J.cols >= ((size_t)1 << 22) && J.cols >= 4 * J.k && J.k >= 2 * HS_SKETCH_ZETA;
       const int nblk = (J.k + HS_PB - 1) / HS_PB, ncand = ((J.rows + 127) / 128 + 1) * HS_PB;
       offOm[a] = nOm;
-      nOm += (size_t)J.cols * J.k + 32;
+      if (!sparse[a]) nOm += (size_t)J.cols * J.k + 32;
       offInv[a] = nInv;
       nInv += (size_t)2 * nblk * HS_PB * HS_PB;
       offInt[a] = nInt;
@@ -119,7 +175,7 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
     NodeDesc<T>* dn;
     GemmProb<T>* dgp;
     DiagJob<T>* ddj;
-    LRB_HIP(g.alloc(&dOm, sizeof(T) * nOm));
+    LRB_HIP(g.alloc(&dOm, sizeof(T) * std::max<size_t>(nOm, 32)));
     LRB_HIP(g.alloc(&dInv, sizeof(T) * nInv));
     LRB_HIP(g.alloc(&dInt, sizeof(int) * nInt));
     LRB_HIP(g.alloc(&dDg, sizeof(double) * nDg));
@@ -127,7 +183,7 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
     LRB_HIP(g.alloc(&dgp, sizeof(GemmProb<T>) * nj));
     LRB_HIP(g.alloc(&ddj, sizeof(DiagJob<T>) * nj));
     LRB_HIP(hipMemsetAsync(dInt, 0, sizeof(int) * nInt, s));
-    const size_t nrand = nOm * (sizeof(T) / 8);
+    const size_t nrand = std::max<size_t>(nOm, 32) * (sizeof(T) / 8);
     hipLaunchKernelGGL(randn_fill_kernel, dim3((unsigned)((nrand + 255) / 256)), dim3(256), 0, s, (double*)dOm, nrand,
                        jobs[todo[0]].seed + 0x1000ull * pass);
     // ---- per block: the sketch Y (kept: it becomes the packed L\U that holds C), descriptors ------------------------
@@ -145,7 +201,7 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
         return -7;
       }
       const int nblk = (J.k + HS_PB - 1) / HS_PB, ncand = ((J.rows + 127) / 128 + 1) * HS_PB;
-      hgp[a] = GemmProb<T>{J.X, dOm + offOm[a], Y[a], J.rows, J.k, J.cols, J.ldx, J.cols, ldp[a]};
+      hgp[a] = GemmProb<T>{J.X, dOm + offOm[a], Y[a], sparse[a] ? 0 : J.rows, J.k, J.cols, J.ldx, J.cols, ldp[a]};  // (M = 0: the GEMM skips a block that is sketched sparsely)
       NodeDesc<T>& d = hn[a];
       memset(&d, 0, sizeof d);
       d.LF = Y[a];
@@ -186,7 +242,58 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
       hs_set_error(-6, 0, "upload of the compression descriptors failed: %s", hipGetErrorString(e));
       return -6;
     }
-    launch_gemm_probs<T>(dgp, nj, maxrows, maxk, 0, s);  // Y = X * Omega, all blocks
+    launch_gemm_probs<T>(dgp, nj, maxrows, maxk, 0, s);  // Y = X * Omega, all blocks with a Gaussian Omega
+    {
+      std::vector<SparseSketchJob<T>> sj;
+      int smaxrows = 0, smaxk = 0;
+      for (int a = 0; a < nj; ++a) {
+        if (!sparse[a]) continue;
+        const LowRankJob<T>& J = jobs[todo[a]];
+        SparseSketchJob<T> q;
+        q.X = J.X; q.Y = Y[a]; q.ldx = J.ldx; q.ldy = ldp[a]; q.rows = J.rows; q.cols = J.cols; q.k = J.k;
+        q.seed = J.seed * 0x9E3779B97F4A7C15ull + 0x5bd1e995ull * (unsigned long long)(pass + 1);
+        q.scale = std::sqrt((double)J.k / HS_SKETCH_ZETA);
+        // pi_t(j) = (a_t j + b_t) mod cols with gcd(a_t, cols) = 1; the kernel walks the inverse permutation
+        unsigned long long x = q.seed ^ 0xD1B54A32D192ED03ull;
+        auto next = [&]() {
+          x += 0x9E3779B97F4A7C15ull;
+          unsigned long long z = x;
+          z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+          z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+          return z ^ (z >> 31);
+        };
+        const long long n = J.cols;
+        for (int t = 0; t < HS_SKETCH_ZETA; ++t) {
+          long long at;
+          do {
+            at = 1 + (long long)(next() % (unsigned long long)std::max<long long>(n - 1, 1));
+          } while (std::gcd(at, n) != 1);
+          // modular inverse by the extended Euclidean algorithm
+          long long r0 = n, r1 = at, t0 = 0, t1 = 1;
+          while (r1 != 0) {
+            const long long qd = r0 / r1, r2 = r0 - qd * r1, t2 = t0 - qd * t1;
+            r0 = r1; r1 = r2; t0 = t1; t1 = t2;
+          }
+          q.ainv[t] = (unsigned int)((t0 % n + n) % n);
+          q.b[t] = (unsigned int)(next() % (unsigned long long)n);
+        }
+        sj.push_back(q);
+        smaxrows = std::max(smaxrows, J.rows);
+        smaxk = std::max(smaxk, J.k);
+      }
+      if (!sj.empty()) {
+        SparseSketchJob<T>* dsj = nullptr;
+        LRB_HIP(g.alloc(&dsj, sizeof(SparseSketchJob<T>) * sj.size()));
+        hipError_t es = hipMemcpyAsync(dsj, sj.data(), sizeof(SparseSketchJob<T>) * sj.size(), hipMemcpyHostToDevice, s);
+        if (es == hipSuccess) es = hipStreamSynchronize(s);  // the source is a host vector
+        if (es != hipSuccess) {
+          free_Y();
+          hs_set_error(-6, 0, "upload of the sketch descriptors failed: %s", hipGetErrorString(es));
+          return -6;
+        }
+        hipLaunchKernelGGL(sparse_sketch_kernel<T>, dim3((unsigned)((smaxrows + 255) / 256), (unsigned)smaxk, (unsigned)sj.size()), dim3(256), 0, s, (const SparseSketchJob<T>*)dsj);
+      }
+    }
     if (keep_sketch) {  // the orthogonalisation that refines rank and interpolation reads the sketch itself, not its L\U
       for (int a = 0; a < nj; ++a) {
         const LowRankJob<T>& J = jobs[todo[a]];

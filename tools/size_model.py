@@ -105,6 +105,7 @@ def model(N, kind, nranks, nmax, swlevel, alpha, leaf, verbose=False):
     flows = ["a", "b", "b1d", "mf1", "mf2", "mf3"]
     per = {f: [0.0] * nranks for f in flows}      # persistent bytes per rank
     trans = {f: [0.0] * nranks for f in flows}    # largest transient (Schur scratch / front being compressed) per rank
+    scratch = {f: {} for f in flows}              # (rank, level) -> bytes of the scratch fronts of the compressed fronts of that level (hs_api.hip NodeH::cfront)
     for i, x in enumerate(nodes):
         ni, nb, lv = x["ni"], x["nb"], x["level"]
         dense = dense_front_elems(ni, nb) * sz
@@ -131,8 +132,10 @@ def model(N, kind, nranks, nmax, swlevel, alpha, leaf, verbose=False):
                 per[f][first] += dense
                 trans[f][first] = max(trans[f][first], 2 * sb)
                 continue
-            if not kids_flagged:  # transition front: eliminated on its dense front (kept: hs_compress.h), S compressed to HSS afterwards
-                per[f][first] += dense
+            if not kids_flagged:  # transition front: eliminated on a SCRATCH front, keeps the compact LU of Aii + low-rank L, R; S compressed to HSS afterwards
+                per[f][first] += (dense_front_elems(ni, 0) + (ni + nb) * (rL + rR)) * sz
+                key = (first, lv)
+                scratch[f][key] = scratch[f].get(key, 0.0) + ((ni + nb) * ni + ni * nb) * sz
                 trans[f][first] = max(trans[f][first], 2 * sb + hss_elems(nb, leaf, alpha) * sz)
                 continue
             lr = (ni + nb) * (rL + rR) * sz  # C_L, Z_L, W = D^-1 C_R, Z_R
@@ -149,6 +152,8 @@ def model(N, kind, nranks, nmax, swlevel, alpha, leaf, verbose=False):
             trans[f][first] = max(trans[f][first], s_h + kids + 2 * ni * 4096 * sz)
     out = {}
     for f in flows:
+        for r in range(nranks):
+            trans[f][r] += max([v for (rr, _), v in scratch[f].items() if rr == r], default=0.0)
         tot = [per[f][r] + trans[f][r] for r in range(nranks)]
         out[f] = dict(max_GiB=max(tot) / 2**30, min_GiB=min(tot) / 2**30, persistent_max_GiB=max(per[f]) / 2**30)
     top = sorted(((x["level"], x["ni"], x["nb"]) for x in nodes if x["level"] <= 5), key=lambda t: t[0])
