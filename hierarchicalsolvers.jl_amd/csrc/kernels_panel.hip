@@ -689,6 +689,170 @@ __global__ __launch_bounds__(256) void panel_pivot_opt_kernel(const NodeDesc<dou
 }
 
 // ------------------------------------------------------------------------------------------------
+// panel_pivot, OPTIMISTIC pivoting, ComplexF64 -- the merged kernel of the complex path (round 3).
+// The general kernel (above) cost 190 us alone and 260-490 us next to a GEMM per 32-column panel -- the longest link of the complex panel
+// chain, 0.5 s of device time per factorization of Helmholtz 112^3 (profiles/r03_*_before_zchain.csv) -- because its two 32-step loops run on 256
+// threads with two workgroup barriers per step, after a separate pivot-search elimination and a trip of the swaps through global memory.
+// panel_pivot_opt_kernel's register formulation is 4x the straight-line code for complex numbers (270 KB, slower than what it replaces), so
+// here the rows live in LDS and ONE wave walks each dependent loop -- LDS operations of a wave complete in order, no barrier inside a loop --
+// with the two halves of the wave sharing a row's columns:
+//   wave 0   one elimination with the pivot search inside it (lane & 31 = row, implicit permutation); meanwhile waves 1-3 load the side blocks
+//   then     wave 1: inv(L)    wave 2: inv(U)    wave 0: ipiv, rperm, the L\U block, the pivoted rows of the previous 32 columns
+//   and      U12 = inv(L) * (P A12) by all threads (fuse & 1).     Two workgroup barriers per panel.
+// ------------------------------------------------------------------------------------------------
+#define HS_ZP_LD (HS_PB + 1)
+#define HS_LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  // a wave's LDS writes have landed before its next (cross-lane) reads
+__global__ __launch_bounds__(256) void panel_pivot_opt_z_kernel(const NodeDesc<cplx>* __restrict__ nodes, int pb, int fuse) {
+  __builtin_amdgcn_s_setprio(3);
+  const NodeDesc<cplx> nd = nodes[blockIdx.y];
+  const int c0 = pb * HS_PB;
+  if (c0 >= nd.ni) return;
+  const int w = min(HS_PB, nd.ni - c0);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int w2 = (fuse & 1) ? max(0, min(HS_PB, nd.ni - (c0 + HS_PB))) : 0;
+  const bool prev = (fuse & 2) && c0 >= HS_PB;
+  const size_t ld = nd.ldl;
+  cplx* const LF = nd.LF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char zp_smem[];
+  cplx* s_a = reinterpret_cast<cplx*>(zp_smem);  // the block, rows in ORIGINAL order; after the elimination L\U, row of pivot k = s_pl[k] - c0
+  cplx* s_n = s_a + HS_PB * HS_ZP_LD;            // rows c0.. of the NEXT 32 columns as loaded (fuse & 1)
+  cplx* s_p = s_n + HS_PB * HS_ZP_LD;            // rows c0.. of the PREVIOUS 32 columns as loaded (fuse & 2)
+  cplx* s_il = s_p + HS_PB * HS_ZP_LD;           // inv(L), pivoted order
+  cplx* s_iu = s_il + HS_PB * HS_ZP_LD;          // inv(U)
+  int* s_pl = reinterpret_cast<int*>(s_iu + HS_PB * HS_ZP_LD);
+  int* s_piv = s_pl + HS_PB;
+  int* s_where = s_piv + HS_PB;
+  int* s_what = s_where + HS_PB;
+  int* s_r = s_what + HS_PB;
+#define ZA(i, j) s_a[(i) * HS_ZP_LD + (j)]
+  const int i = lane & 31, hf = lane >> 5;
+
+  // ---- load: wave 0 the diagonal block (identity-padded), waves 1-3 the side blocks and rperm -------------------------------------------------
+  if (wave == 0) {
+    for (int j = hf; j < HS_PB; j += 2) ZA(i, j) = (i < w && j < w) ? gld(LF + (size_t)(c0 + i) + (size_t)(c0 + j) * ld) : (i == j ? Scal<cplx>::one() : Scal<cplx>::zero());
+  } else if (wave == 1) {
+    if (w2 > 0)
+      for (int r = hf; r < HS_PB; r += 2) s_n[r * HS_ZP_LD + i] = (r < w && i < w2) ? gld(LF + (size_t)(c0 + r) + (size_t)(c0 + HS_PB + i) * ld) : Scal<cplx>::zero();
+  } else if (wave == 2) {
+    if (prev)
+      for (int r = hf; r < HS_PB; r += 2) s_p[r * HS_ZP_LD + i] = (r < w) ? gld(LF + (size_t)(c0 + r) + (size_t)(c0 - HS_PB + i) * ld) : Scal<cplx>::zero();
+  } else {
+    if (lane < HS_PB) s_r[lane] = (lane < w) ? nd.rperm[c0 + lane] : 0;
+  }
+  // ---- 1. elimination with the pivot search inside (wave 0; both halves of the wave work on row i, columns of their parity) -----------------
+  if (wave == 0) {
+    HS_LDS_ORDER();
+    bool alive = i < w;
+    bool bad = false;
+    for (int k = 0; k < HS_PB; ++k) {
+      if (k < w) {
+        unsigned long long key = 0;
+        if (alive && hf == 0) key = ((unsigned long long)__double_as_longlong(Scal<cplx>::abs1(ZA(i, k))) & ~0xffull) | (unsigned long long)(255 - i);
+        const unsigned long long best = wave_max_u64(key);
+        int win;
+        if ((best >> 8) != 0) {
+          win = 255 - (int)(best & 0xff);
+        } else {  // the column is zero on every row still in play: the block is singular on its own rows -> the level is redone
+          bad = true;
+          const unsigned long long m = __ballot(alive && hf == 0);
+          win = m ? (__ffsll((long long)m) - 1) : 0;
+        }
+        win = __builtin_amdgcn_readfirstlane(win);
+        if (lane == 0) s_pl[k] = c0 + win;
+        const cplx piv = ZA(win, k);
+        const bool zero_piv = (best >> 8) == 0;
+        if (alive && i != win && !zero_piv) {
+          const cplx l = ZA(i, k) / piv;
+          for (int j = k + 1 + hf; j < HS_PB; j += 2) ZA(i, j) = Scal<cplx>::fnma(l, ZA(win, j), ZA(i, j));
+          HS_LDS_ORDER();
+          if (hf == 0) ZA(i, k) = l;  // (after both halves have read the old value)
+        }
+        if (i == win) alive = false;
+        HS_LDS_ORDER();
+      } else if (lane == 0) {
+        s_pl[k] = c0 + k;
+      }
+    }
+    if (bad && lane == 0 && nd.growth) *nd.growth = 1;
+  }
+  __syncthreads();
+#define ZLU(k, j) s_a[(s_pl[k] - c0) * HS_ZP_LD + (j)]  // L\U in pivoted order
+  // ---- 2. inverses (waves 1, 2); swaps / rperm / the L\U block / the previous columns (wave 0) ------------------------------------------------
+  if (wave == 0) {
+    if (lane == 0) {
+      for (int k = 0; k < HS_PB; ++k) {
+        s_where[k] = c0 + k;
+        s_what[k] = c0 + k;
+      }
+      for (int k = 0; k < w; ++k) {
+        const int r = s_pl[k];
+        const int target = c0 + k;
+        const int p = s_where[r - c0];
+        s_piv[k] = p;
+        if (p != target) {
+          const int q = s_what[k];
+          s_what[k] = r;
+          s_what[p - c0] = q;
+          s_where[r - c0] = target;
+          s_where[q - c0] = p;
+        }
+      }
+    }
+    HS_LDS_ORDER();
+    if (lane < w) {
+      nd.ipiv[c0 + lane] = s_piv[lane];
+      nd.rperm[c0 + lane] = s_r[s_pl[lane] - c0];
+    }
+    for (int j = hf; j < HS_PB; j += 2) {
+      if (i < w && j < w) gst(LF + (size_t)(c0 + i) + (size_t)(c0 + j) * ld, ZLU(i, j));
+      if (prev && i < w) gst(LF + (size_t)(c0 + i) + (size_t)(c0 - HS_PB + j) * ld, s_p[(s_pl[i] - c0) * HS_ZP_LD + j]);
+    }
+  } else if (wave == 1) {
+    // inv(L): the row operations that reduce L to I applied to I (row i of pivoted order in LDS; columns split over the two halves)
+    for (int j = hf; j < HS_PB; j += 2) s_il[i * HS_ZP_LD + j] = (i == j) ? Scal<cplx>::one() : Scal<cplx>::zero();
+    HS_LDS_ORDER();
+    for (int k = 0; k < HS_PB - 1; ++k) {
+      if (i > k) {
+        const cplx l = ZLU(i, k);
+        for (int j = hf; j <= k; j += 2) s_il[i * HS_ZP_LD + j] = Scal<cplx>::fnma(l, s_il[k * HS_ZP_LD + j], s_il[i * HS_ZP_LD + j]);
+      }
+      HS_LDS_ORDER();
+    }
+    for (int j = hf; j < HS_PB; j += 2) gst(nd.invL + (size_t)pb * HS_PB * HS_PB + i + j * HS_PB, s_il[i * HS_ZP_LD + j]);
+  } else if (wave == 2) {
+    // inv(U) by back substitution in rank-1 form (a zero pivot counts as 1: the front is already flagged)
+    for (int j = hf; j < HS_PB; j += 2) s_iu[i * HS_ZP_LD + j] = (i == j) ? Scal<cplx>::one() : Scal<cplx>::zero();
+    HS_LDS_ORDER();
+    for (int p = HS_PB - 1; p >= 0; --p) {
+      cplx d = ZLU(p, p);
+      if (Scal<cplx>::abs1(d) == 0.0) d = Scal<cplx>::one();
+      if (i == p)
+        for (int j = p + hf; j < HS_PB; j += 2) s_iu[p * HS_ZP_LD + j] = s_iu[p * HS_ZP_LD + j] / d;
+      HS_LDS_ORDER();
+      if (i < p) {
+        const cplx u = ZLU(i, p);
+        for (int j = p + hf; j < HS_PB; j += 2) s_iu[i * HS_ZP_LD + j] = Scal<cplx>::fnma(u, s_iu[p * HS_ZP_LD + j], s_iu[i * HS_ZP_LD + j]);
+      }
+      HS_LDS_ORDER();
+    }
+    for (int j = hf; j < HS_PB; j += 2) gst(nd.invU + (size_t)pb * HS_PB * HS_PB + i + j * HS_PB, s_iu[i * HS_ZP_LD + j]);
+  }
+  if (w2 > 0) {  // U12 = inv(L11) * (P*A12) (fuse & 1), every thread four entries
+    __syncthreads();
+    for (int e = t; e < HS_PB * HS_PB; e += 256) {
+      const int ii = e & 31, j = e >> 5;
+      if (ii < w && j < w2) {
+        cplx u = Scal<cplx>::zero();
+        for (int q = 0; q <= ii; ++q) u = Scal<cplx>::fma(s_il[ii * HS_ZP_LD + q], s_n[(s_pl[q] - c0) * HS_ZP_LD + j], u);
+        gst(LF + (size_t)(c0 + ii) + (size_t)(c0 + HS_PB + j) * ld, u);
+      }
+    }
+  }
+#undef ZA
+#undef ZLU
+}
+
+// ------------------------------------------------------------------------------------------------
 // group256: the WHOLE panel chain of a 256-column group on its 256 x 256 diagonal block in ONE launch (Float64, optimistic pivoting).
 // Sched::lu_rec (diagonal-block-first groups) ran it as 28 dependent launches -- 8 x (pivot, L21), the swaps, the 64 / 128-row solves and the
 // K <= 128 updates of the recursion, every one a single workgroup -- which next to a running GEMM cost 1.9 ms per group (tools/factor_trace.sh:
@@ -1197,6 +1361,19 @@ void launch_panel_pivot(const NodeDesc<T>* dnodes, int nbatch, int pb, int fuse,
     static const bool merged = !(getenv("HS_PANEL_OPT") && getenv("HS_PANEL_OPT")[0] == '0');  // 0: the general kernel for optimistic panels too
     if ((fuse & 4) && merged) {
       hipLaunchKernelGGL(panel_pivot_opt_kernel, dim3(1, nbatch), dim3(256), 0, s, dnodes, pb, fuse);
+      return;
+    }
+  }
+  if constexpr (sizeof(T) == 16) {
+    static const bool merged_z = !(getenv("HS_PANEL_OPT_Z") && getenv("HS_PANEL_OPT_Z")[0] == '0');  // 0: the general kernel for optimistic complex panels
+    if ((fuse & 4) && merged_z) {
+      constexpr int lds = 5 * HS_PB * HS_ZP_LD * (int)sizeof(cplx) + 5 * HS_PB * (int)sizeof(int);
+      static bool attr = false;
+      if (!attr) {  // 85 KB: above the 64 KB a kernel gets without the opt-in
+        (void)hipFuncSetAttribute((const void*)panel_pivot_opt_z_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+      }
+      hipLaunchKernelGGL(panel_pivot_opt_z_kernel, dim3(1, nbatch), dim3(256), lds, s, dnodes, pb, fuse);
       return;
     }
   }
