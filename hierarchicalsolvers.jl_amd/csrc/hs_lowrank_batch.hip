@@ -58,7 +58,7 @@ struct SparseSketchJob {
   T* Y;
   int ldx, ldy, rows, cols, k;
   unsigned long long seed;
-  unsigned int ainv[HS_SKETCH_ZETA], b[HS_SKETCH_ZETA];
+  unsigned int ainv[HS_SKETCH_ZETA], b[HS_SKETCH_ZETA], step[HS_SKETCH_ZETA];  // step = ainv * k mod cols: pi^-1(p + k) = pi^-1(p) + step (mod cols)
   double scale;
 };
 template <class T>
@@ -73,13 +73,15 @@ __global__ __launch_bounds__(256) void sparse_sketch_kernel(const SparseSketchJo
   const unsigned long long n = (unsigned long long)J.cols;
 #pragma unroll 1
   for (int t = 0; t < HS_SKETCH_ZETA; ++t) {
-    const unsigned long long ai = J.ainv[t], bt = J.b[t];
-#pragma unroll 4
+    const unsigned long long ai = J.ainv[t], bt = J.b[t], st = J.step[t];
+    unsigned long long j = (ai * (((unsigned long long)c + n - bt) % n)) % n;  // pi_t^-1(c); the walk below needs no division (uniform over the workgroup)
+#pragma unroll 8
     for (int p = c; p < J.cols; p += J.k) {  // positions c, c + k, ... of the permuted order: the columns of bucket c
-      const unsigned long long j = (ai * (((unsigned long long)p + n - bt) % n)) % n;   // pi_t^-1(p), uniform over the workgroup
       const unsigned long long h = mix64(J.seed ^ ((unsigned long long)(t + 1) << 48) ^ j);
       const T v = gld(xr + (size_t)j * J.ldx);
       acc = (h & 1ull) ? acc + v : acc - v;
+      j += st;
+      j = j >= n ? j - n : j;
     }
   }
   if (live) J.Y[(size_t)row + (size_t)c * J.ldy] = acc * from_scale<T>(J.scale);
@@ -276,6 +278,7 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
           }
           q.ainv[t] = (unsigned int)((t0 % n + n) % n);
           q.b[t] = (unsigned int)(next() % (unsigned long long)n);
+          q.step[t] = (unsigned int)(((unsigned long long)q.ainv[t] * (unsigned long long)(J.k % n)) % (unsigned long long)n);
         }
         sj.push_back(q);
         smaxrows = std::max(smaxrows, J.rows);

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT
 tools/pmc_bench.sh poisson3d_128 > gpurun_out/final_pmc.log 2>&1 || { tail -5 gpurun_out/final_pmc.log; exit 1; }
 tail -1 gpurun_out/final_pmc.log | cut -c1-400
-cp gpurun_out/r02_poisson3d_128_gemm_pmc_traffic.json profiles/r02_poisson3d_128_gemm_pmc_traffic.json  # the bench line below reports it (same head, same launch count)
+cp gpurun_out/r03_poisson3d_128_gemm_pmc_traffic.json profiles/r03_poisson3d_128_gemm_pmc_traffic.json  # the bench line below reports it (same head, same launch count)
 cd /tmp; export TMPDIR=/tmp; rm -rf $R/gpurun_out/prof_final; mkdir -p $R/gpurun_out/prof_final; cd $R
 timeout -k 10 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_final -- python3 bench.py --no-cpu-baseline --no-oneshot --metric-workload "" --steps 3 --warmup 1 > gpurun_out/prof_final/bench.log 2>&1 || { tail -5 gpurun_out/prof_final/bench.log; exit 1; }
 DB=$(find gpurun_out/prof_final -name "*results.db" | head -1)
