@@ -215,9 +215,9 @@ NAMED = {
     "helmholtz3d_128": ((128, 128, 128), "helmholtz", 4096),  # 278 GiB of dense complex factors: needs >= 2 GPUs
     # the 8-GPU compressed configurations (hs_options.mf over ranks; tools/size_model.py: per-rank bytes with the rank constant measured on
     # Helmholtz 112^3 at 1e-4): leaves of 1,024 DOFs -- with 4,096 the dense leaf blocks alone are 137 GiB per rank at 256^3
-    "helmholtz3d_192": ((192, 192, 192), "helmholtz", 1024),  # every mf flow fits 8 x 288 GB (mf = 2: 121 GiB on the busiest rank)
-    "helmholtz3d_224": ((224, 224, 224), "helmholtz", 1024),  # mf = 2 only (201 GiB on the busiest rank)
-    "helmholtz3d_256": ((256, 256, 256), "helmholtz", 1024),  # BASELINE.json config 5: modelled at 313 GiB per rank with mf = 2 -- does NOT fit yet
+    "helmholtz3d_192": ((192, 192, 192), "helmholtz", 1024),  # mf = 2 / 3 fit 8 x 288 GB (130 / 151 GiB on the busiest rank)
+    "helmholtz3d_224": ((224, 224, 224), "helmholtz", 1024),  # mf = 2 only (217 GiB on the busiest rank)
+    "helmholtz3d_256": ((256, 256, 256), "helmholtz", 1024),  # BASELINE.json config 5: modelled at 338 GiB per rank with mf = 2 -- does NOT fit yet
 }
 
 
