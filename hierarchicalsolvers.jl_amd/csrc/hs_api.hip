@@ -1176,7 +1176,7 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
     // pivoting among its own 32 rows; if any front raised its growth flag the level is assembled again and eliminated with
     // tournament pivoting, and the handle stops trying (a matrix that needs real pivoting needs it everywhere).
     static const bool opt_env = !(getenv("HS_OPTIMISTIC") && getenv("HS_OPTIMISTIC")[0] == '0');
-    bool try_opt = opt_env && h->optimistic && L.ndense > 0;
+    bool try_opt = opt_env && h->optimistic && (L.ndense > 0 || L.nplain > 0);
     const NodeH* dx = (L.mine.size() == 1 && h->nodes[L.mine[0]].dist) ? &h->nodes[L.mine[0]] : nullptr;  // a front eliminated by its group
     DistFront<T> DF;
     if (dx) {
@@ -1243,19 +1243,22 @@ static void numeric_levels(hs_handle* h, int lv_from, int lv_to) {
       else
         sch.factor_fronts();
     }
+    // the interior blocks of the compressed fronts: the same optimistic attempt, the same redo (hs_compress.h, phase 1)
+    if (L.nplain > 0)
+      factor_compressed_level<T>(h, L.mine.data() + L.ndense, L.nplain, dn + L.ndense, (const SolveNode<T>*)h->d_solve + L.desc_off + L.ndense, 1, try_opt && attempt == 0);
       if (!(try_opt && attempt == 0)) break;
       std::vector<int> gr(h->nnodes);
       HS_HIP(hipMemcpyAsync(gr.data(), h->d_growth, sizeof(int) * h->nnodes, hipMemcpyDeviceToHost, s));
       HS_HIP(hipStreamSynchronize(s));
       static const bool force_redo = getenv("HS_OPTIMISTIC_FORCE_REDO") != nullptr;  // tests: exercise the redo machinery
       bool redo = force_redo;
-      for (int k = 0; k < L.ndense; ++k) redo = redo || gr[L.mine[k]] != 0;
+      for (int k = 0; k < L.ndense + L.nplain; ++k) redo = redo || gr[L.mine[k]] != 0;
       if (dx) redo = dist_group_or(h->comm, h->d_gflags, dx->glo, dx->gcnt, h->rank, redo ? 1 : 0, h->stream_comm) != 0;
       if (!redo) break;
       h->optimistic = false;
       if (h->opts.verbose) fprintf(stderr, "[hs] level %d: a pivot outside the diagonal block was needed; redoing the level with tournament pivoting\n", lv);
     }
-    if (L.nplain > 0) factor_compressed_level<T>(h, L.mine.data() + L.ndense, L.nplain, dn + L.ndense, (const SolveNode<T>*)h->d_solve + L.desc_off + L.ndense);  // hs_compress.h
+    if (L.nplain > 0) factor_compressed_level<T>(h, L.mine.data() + L.ndense, L.nplain, dn + L.ndense, (const SolveNode<T>*)h->d_solve + L.desc_off + L.ndense, 2);  // hs_compress.h, steps B-F
     if (nb_ > L.ndense + L.nplain) factor_hss_fronts<T>(h, L.mine.data() + L.ndense + L.nplain, nb_ - L.ndense - L.nplain, dn + L.ndense + L.nplain);  // hs_hssfront.h
     {  // F2: a flagged front eliminated densely (a leaf) still hands its S on as an HSS matrix (factorization.jl:45-59)
       std::vector<int> todo;

@@ -53,8 +53,13 @@ static void free_lowrank_any(hs_handle* h) {
 // eliminate the compressed fronts of one level: `dn` = their descriptors on the device (fronts already assembled),
 // `ids` their node ids.  Steps A, C, D, E run as ONE batch over the fronts (the panel chains of single fronts would
 // otherwise run back to back); B and F are per front.
+// phase 0: everything; 1: step A only (the LU of every Aii), with OPTIMISTIC pivoting when `optimistic` is set -- the caller checks the fronts'
+// growth flags afterwards and, if one went up, assembles the level again and repeats the step with the tournament (hs_api.hip numeric_levels: the same
+// redo as for the dense fronts.  Until round 3 the interior blocks of the compressed fronts always ran the tournament path: full-height panels, 2-4
+// dependent tournament rounds and the general pivot kernel per 32 columns -- at Helmholtz 112^3 their LUs took 570 ms for 280 ms of GEMM);
+// 2: steps B-F after a phase-1 call.
 template <class T>
-static void factor_compressed_level(hs_handle* h, const int* ids, int count, const NodeDesc<T>* dn, const SolveNode<T>* sn) {
+static void factor_compressed_level(hs_handle* h, const int* ids, int count, const NodeDesc<T>* dn, const SolveNode<T>* sn, int phase = 0, bool optimistic = false) {
   if (count <= 0) return;
   hipStream_t s = h->stream;
   static const bool vt = getenv("HS_VERBOSE_COMPRESS") != nullptr;  // per-step wall times (diagnostics; adds syncs)
@@ -109,14 +114,16 @@ static void factor_compressed_level(hs_handle* h, const int* ids, int count, con
     tmp[i].finalize();
   }
   HS_HIP(hipMemcpy(dd, tmp.data(), sizeof(NodeDesc<T>) * count, hipMemcpyHostToDevice));
-  {
+  if (phase != 2) {
     std::vector<int> hni(count), hnb(count, 0);
     for (int i = 0; i < count; ++i) hni[i] = hd[i].ni;
     Sched<T> sA{dd, count, maxni, 0, maxni, s, &h->prof, hni.data(), hnb.data(), h->stream2, 0, h->stream_la, h->stream2m};
     sA.sn = sn;  // solve descriptors of the same fronts: the 256x256 inverse diagonal blocks are built inside lu_rec
+    sA.optimistic = optimistic;
     sA.factor_fronts();
+    lap(optimistic ? "A: LU(Aii), optimistic pivoting" : "A: LU(Aii)");
   }
-  lap("A: LU(Aii)");
+  if (phase == 1) return;
 
   // B. low-rank forms of the two off-diagonal blocks (tolerances of factorization.jl:99-100).  The sketch width
   // starts from the rank the same front had in the previous factorization of this handle (kest, else 128, the first time).
