@@ -76,7 +76,7 @@ EXPORTS = [
     "hs_analyze", "hs_plan", "hs_numeric_begin", "hs_numeric_levels", "hs_numeric_end", "hs_solve_fwd_levels", "hs_solve_bwd_levels",
     "hs_nlevels", "hs_cut_level", "hs_node_owner", "hs_num_exchanges", "hs_exchange_info", "hs_set_schur_buffer",
     "hs_pack_bnd", "hs_unpack_bnd", "hs_extract_owned", "hs_gmres_d", "hs_gmres_z",
-    "hs_exchange_kind", "hs_schur_pack_size", "hs_schur_pack", "hs_schur_unpack", "hs_flow_info", "hs_hss_pack_size", "hs_hss_pack", "hs_hss_unpack",
+    "hs_exchange_kind", "hs_schur_pack_size", "hs_schur_pack", "hs_schur_unpack", "hs_flow_info", "hs_hss_pack_size", "hs_hss_pack", "hs_hss_unpack", "hs_hss_qr_order",
     "hs_comm_unique_id", "hs_comm_create_rccl", "hs_comm_create_host", "hs_comm_free", "hs_comm_kind", "hs_comm_selftest", "hs_comm_bandwidth", "hs_set_comm",
     "hs_symbolic_from_elimtree", "hs_symbolic_from_graph", "hs_symbolic_size", "hs_symbolic_perm", "hs_symbolic_tree", "hs_symbolic_free",
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_compress_lru_multi_d", "hs_hss_compress_lru_multi_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
@@ -161,6 +161,8 @@ def lib():
     L.hs_schur_unpack.restype = C.c_int
     L.hs_flow_info.argtypes = [vp, p_i64]
     L.hs_flow_info.restype = C.c_int
+    L.hs_hss_qr_order.argtypes = [C.c_int]
+    L.hs_hss_qr_order.restype = C.c_int
     L.hs_hss_pack_size.argtypes = [vp, p_i64]
     L.hs_hss_pack_size.restype = C.c_int
     L.hs_hss_pack.argtypes = [vp, vp, i64, vp]

@@ -25,6 +25,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <vector>
 
 #include "../../include/hs_hss.h"
@@ -666,6 +667,8 @@ struct CholJob {
   int b, first;
   double floor_abs;  // nothing below this is accepted: the round-off level of the block's samples (0: none)
   double cond, noise_rel;  // HS_CHOL_COND, HS_NOISE_REL (run-time copies: diagnostics may override them)
+  const double* next2 = nullptr;  // QrJob::norm_select: squared residual norm of the largest row OUTSIDE the window (an upper bound: it is
+  double theta2 = 0.0;            // downdated afterwards); a pivot below theta * that is not accepted -- the greedy order of a pivoted QR, relaxed by theta
 };
 template <class T>
 __device__ inline double real_of(T a);
@@ -704,6 +707,7 @@ __global__ __launch_bounds__(64) void chol_block_kernel(const CholJob<T>* __rest
   if (t == 0) s_nacc = 0;
   __syncthreads();
   double top = j.first ? 0.0 : *j.top, d0 = 0.0, tau = 0.0;
+  const double out2 = j.next2 ? j.theta2 * *j.next2 : 0.0;
   for (int k = 0; k < b; ++k) {
     if (t == 0) {  // largest remaining diagonal entry
       int best = k;
@@ -724,6 +728,7 @@ __global__ __launch_bounds__(64) void chol_block_kernel(const CholJob<T>* __rest
       tau = fmax(fmax(j.atol, j.rtol * fmax(top, j.scale_floor)), fmax(j.floor_abs, j.noise_rel * top));
     }
     if (!(dk > tau) || !(dk > j.cond * d0) || !(dk > 0.0)) break;  // uniform: every thread sees the same dk
+    if (k > 0 && dk * dk < out2) break;  // a row outside the window is (possibly) further from the span: it goes first
     // symmetric swap k <-> pv of the full square copy (both triangles are maintained) and of the finished columns
     if (pv != k && t < b) {
       if (t == 0) { const int q = perm[k]; perm[k] = perm[pv]; perm[pv] = q; }
@@ -791,6 +796,157 @@ static void launch_chol(const CholJob<T>* d, unsigned n, hipStream_t s) {
   hipLaunchKernelGGL(chol_block_kernel<T>, dim3(n), dim3(64), lds, s, d);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Window selection by DOWNDATED RESIDUAL NORMS (QrJob::norm_select): the step from "tournament order + windowed Cholesky-QR" to a blocked
+// column-pivoted QR (`pqrfact`, src/factorization.jl:171-182, picks the column of largest residual norm at every step).  res2[i] holds the
+// squared residual norm of EVERY row of the block against the rows accepted so far: after a window accepted Q_new, C = M * Q_new^H (one
+// grouped product over all rows -- it is also the block column of L_RS the interpolation needs, so the product at the end disappears) and
+// res2[i] -= |C[i, :]|^2.  The next window is the <= 64 unaccepted rows of largest res2 (within 2^-7 of the largest in norm: what the window's
+// pivoted Cholesky can accept anyway).  A downdated squared norm has lost its digits once it fell by ~1e10: the norms are then recomputed from
+// the explicit residual M - L_RS * Q (LAPACK's xGEQP3 does the same per column).  No pivoted LU of a sketch is needed for the order.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct NormJob {
+  const T* M;
+  int ldm, m, q;
+  double* res2;
+  int minus;  // 0: res2 = |row|^2; 1: res2 = max(res2 - |row|^2, 0)  (M = the new coefficient columns)
+  int* p;     // != null with minus == 0: also p[i] = i (the initial candidate list)
+};
+template <class T>
+__global__ __launch_bounds__(256) void rownorm2_kernel(const NormJob<T>* __restrict__ jobs) {
+  const NormJob<T> j = jobs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= j.m) return;
+  double acc = 0.0;
+  for (int c = 0; c < j.q; ++c) {
+    const T v = j.M[(size_t)i + (size_t)c * j.ldm];
+    if constexpr (sizeof(T) == 16) acc += v.re * v.re + v.im * v.im; else acc += v * v;
+  }
+  if (j.minus) {
+    j.res2[i] = fmax(j.res2[i] - acc, 0.0);
+  } else {
+    j.res2[i] = acc;
+    if (j.p) j.p[i] = i;
+  }
+}
+struct SelJob {
+  int* p;            // candidate list: p[0 : done) accepted, p[done : m) the rest, re-ordered here: the selected rows first
+  int* tmp;          // m ints
+  const double* res2;
+  double* outmax;    // [0] largest res2 among the unaccepted rows, [1] largest res2 among those NOT selected for the window
+  int done, m, want;
+};
+// one workgroup per job: (1) largest res2 of the tail, (2) histogram of log2(max / res2), (3) stable partition of the tail: the first `want`
+// rows of the buckets up to the cutoff in front (the cutoff is the smallest bucket that fills the window, at most 14: 2^-7 in norm)
+__global__ __launch_bounds__(256) void qr_select_kernel(const SelJob* __restrict__ jobs) {
+  const SelJob j = jobs[blockIdx.x];
+  const int t = threadIdx.x, nt = j.m - j.done;
+  __shared__ double s_red[256];
+  __shared__ int s_hist[16], s_cut, s_scan[256], s_base[2];
+  if (nt <= 0) {
+    if (t == 0) j.outmax[0] = j.outmax[1] = 0.0;
+    return;
+  }
+  int* tail = j.p + j.done;
+  double mx = 0.0;
+  for (int e = t; e < nt; e += 256) mx = fmax(mx, j.res2[tail[e]]);
+  s_red[t] = mx;
+  if (t < 16) s_hist[t] = 0;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) s_red[t] = fmax(s_red[t], s_red[t + w]);
+    __syncthreads();
+  }
+  mx = s_red[0];
+  if (t == 0) {
+    j.outmax[0] = mx;
+    j.outmax[1] = 0.0;
+  }
+  if (!(mx > 0.0) || nt <= j.want) return;  // nothing to order: every remaining row is in the window (or all are zero)
+  auto bucket = [&](double v) {
+    if (!(v > 0.0)) return 15;
+    int e;
+    (void)frexp(mx / v, &e);  // mx / v in [2^(e-1), 2^e)
+    return min(max(e - 1, 0), 15);
+  };
+  for (int e = t; e < nt; e += 256) atomicAdd(&s_hist[bucket(j.res2[tail[e]])], 1);
+  __syncthreads();
+  if (t == 0) {
+    int cum = 0, cut = 14;
+    for (int b = 0; b <= 14; ++b) {
+      cum += s_hist[b];
+      if (cum >= j.want) { cut = b; break; }
+    }
+    s_cut = cut;
+    s_base[0] = 0;  // selected so far
+    s_base[1] = 0;  // unselected so far
+  }
+  __syncthreads();
+  const int cut = s_cut;
+  // pass A: how many rows qualify (capped at `want`): the rest of the tail starts behind them
+  int nsel_total = 0;
+  for (int b = 0; b <= cut; ++b) nsel_total += s_hist[b];
+  nsel_total = min(nsel_total, j.want);
+  for (int c0 = 0; c0 < nt; c0 += 256) {
+    const int e = c0 + t;
+    const int row = e < nt ? tail[e] : -1;
+    int f = (row >= 0 && bucket(j.res2[row]) <= cut) ? 1 : 0;
+    s_scan[t] = f;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // inclusive scan of the flags
+      const int v = t >= off ? s_scan[t - off] : 0;
+      __syncthreads();
+      s_scan[t] += v;
+      __syncthreads();
+    }
+    const int incl = s_scan[t], tot = s_scan[255];
+    const int sel_before = s_base[0], uns_before = s_base[1];
+    __syncthreads();
+    if (row >= 0) {
+      const int rank_sel = sel_before + incl - f;  // selected rows before this one
+      const bool take = f && rank_sel < j.want;
+      // position: selected rows in front; everything else behind them in the original order
+      const int taken_before = min(rank_sel, j.want);
+      const int untaken_before = (e - taken_before);  // rows before this one that are not taken = index - taken
+      j.tmp[take ? taken_before : nsel_total + untaken_before] = row;
+    }
+    if (t == 0) {
+      s_base[0] = sel_before + tot;
+      s_base[1] = uns_before + (min(256, nt - c0) - tot);
+    }
+    __syncthreads();
+  }
+  double mo = 0.0;
+  for (int e = t; e < nt; e += 256) {
+    const int row = j.tmp[e];
+    tail[e] = row;
+    if (e >= nsel_total) mo = fmax(mo, j.res2[row]);
+  }
+  __syncthreads();
+  s_red[t] = mo;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) s_red[t] = fmax(s_red[t], s_red[t + w]);
+    __syncthreads();
+  }
+  if (t == 0) j.outmax[1] = s_red[0];
+}
+
+static std::atomic<int> g_qr_order{-1};  // -1: not read yet (HS_QR_ORDER=norm in the environment), 0: the tournament order, 1: residual norms
+static bool qr_norm_order() {
+  int v = g_qr_order.load();
+  if (v < 0) {
+    v = (getenv("HS_QR_ORDER") && getenv("HS_QR_ORDER")[0] == 'n') ? 1 : 0;
+    g_qr_order.store(v);
+  }
+  return v == 1;
+}
+extern "C" int hs_hss_qr_order(int mode) {
+  const int prev = qr_norm_order() ? 1 : 0;
+  if (mode >= 0) g_qr_order.store(mode ? 1 : 0);
+  return prev;
+}
 template <class T>
 struct QrJob {
   const T* M;     // m x q block whose rows are interpolated (ld ldm), left untouched
@@ -799,6 +955,8 @@ struct QrJob {
   int rmax;       // candidates: the first rmax rows of p
   double atol_scale = 1.0;  // the absolute tolerance is multiplied by this (rows of an un-normalised Gaussian sketch are sqrt(k) times longer)
   double floor_abs = 0.0;   // round-off level of the rows of M (absolute): candidates below it are noise whatever the tolerance says
+  bool norm_select = false; // windows chosen by downdated residual norms of ALL rows (qr_select_kernel) instead of taken from the order `p` arrives in;
+                            // `p` is then an output only (qr_refine fills it with 0 .. m-1 first)
   // results
   int r = 0;
   double top = 0.0;      // d_0
@@ -819,6 +977,13 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     int nslab = 0, used = 0;
     int ldq = 2, ldqh = 2, ldl = 2, done = 0, active = 1, maxblk = 0, stall = 0;
     std::vector<std::pair<int, int>> blocks;  // (offset, width) of the accepted blocks
+    // QrJob::norm_select
+    double* res2 = nullptr;  // squared residual norm of every row
+    T* LRS = nullptr;        // m x rmax: coefficients of every row against the accepted rows (the interpolation's L_RS, block column by block column)
+    int ldr = 2;
+    int* ptmp = nullptr;
+    double* dmax = nullptr;  // device: largest res2 of the unaccepted rows at the last selection
+    double refmax = 0.0;     // the same when the norms were last exact
   };
   std::vector<St> st(nj);
   for (int a = 0; a < nj; ++a) {
@@ -847,7 +1012,29 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     S.lperm = tmp.get<int>(HS_QW);
     S.nslab = J.rmax / (HS_QW / 2) + 8;
     S.slab = tmp.get<T>((size_t)S.nslab * 2 * HS_QW * HS_QW);
+    if (J.norm_select) {
+      S.res2 = tmp.get<double>((size_t)J.m);
+      S.ldr = ev(J.m);
+      S.LRS = tmp.get<T>((size_t)S.ldr * J.rmax);
+      S.ptmp = tmp.get<int>((size_t)J.m);
+      S.dmax = tmp.get<double>(2);
+    }
   }
+  std::vector<NormJob<T>> normjobs;
+  auto run_norms = [&]() {
+    if (normjobs.empty()) return;
+    int mm = 0;
+    for (auto& q : normjobs) mm = std::max(mm, q.m);
+    NormJob<T>* d = upload(tmp, normjobs, s);
+    hipLaunchKernelGGL(rownorm2_kernel<T>, dim3((unsigned)((mm + 255) / 256), (unsigned)normjobs.size()), dim3(256), 0, s, (const NormJob<T>*)d);
+    normjobs.clear();
+  };
+  for (int a = 0; a < nj; ++a)
+    if (jobs[a].norm_select && st[a].active) normjobs.push_back(NormJob<T>{jobs[a].M, jobs[a].ldm, jobs[a].m, jobs[a].q, st[a].res2, 0, jobs[a].p});
+  run_norms();
+  std::vector<double> hmax(2 * (size_t)nj, 0.0);
+  double* dmaxall = tmp.get<double>(2 * (size_t)nj);
+  static const double theta = getenv("HS_QR_THETA") ? atof(getenv("HS_QR_THETA")) : 0.5;  // relaxation of the greedy order (1: strict)
   int* dnacc = tmp.get<int>((size_t)nj);
   for (int a = 0; a < nj; ++a) st[a].nacc = dnacc + a;
   std::vector<int> hacc(nj, 0);
@@ -865,6 +1052,16 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       for (int a = 0; a < nj; ++a)
         if (st[a].active) f(a, jobs[a], st[a], std::min(HS_QW, jobs[a].rmax - st[a].done));
     };
+    {  // norm_select: the window's candidates = the unaccepted rows of largest residual norm, moved to the front of the rest of the list
+      std::vector<SelJob> sj;
+      each([&](int a, QrJob<T>& J, St& S, int b) {
+        if (J.norm_select) sj.push_back(SelJob{J.p, S.ptmp, S.res2, dmaxall + 2 * a, S.done, J.m, b});
+      });
+      if (!sj.empty()) {
+        SelJob* dsj = upload(tmp, sj, s);
+        hipLaunchKernelGGL(qr_select_kernel, dim3((unsigned)sj.size()), dim3(256), 0, s, (const SelJob*)dsj);
+      }
+    }
     // W = M[p[done : done+b], :]
     each([&](int, QrJob<T>& J, St& S, int b) { rows.push_back(RowJob<T>{J.M, J.ldm, S.W, HS_QW, J.p + S.done, b, J.q, ROW_GATHER}); });
     if (rows.empty()) break;
@@ -896,13 +1093,14 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       linv[a].push_back(slot);
       linvp[a].push_back(slot + HS_QW * HS_QW);
       cj.push_back(CholJob<T>{S.G, S.L + S.done + (size_t)S.done * S.ldl, S.ldl, slot, slot + HS_QW * HS_QW, S.d + S.done, S.top, J.p + S.done, S.lperm, S.nacc, atol * J.atol_scale,
-                              rtol, scale_floor, b, S.done == 0 ? 1 : 0, J.floor_abs, chol_cond, noise_rel()});
+                              rtol, scale_floor, b, S.done == 0 ? 1 : 0, J.floor_abs, chol_cond, noise_rel(), J.norm_select ? dmaxall + 2 * a + 1 : nullptr, theta * theta});
     });
     run_gemms(tmp, g, 0, s);
     CholJob<T>* dcj = upload(tmp, cj, s);
     launch_chol<T>(dcj, (unsigned)cj.size(), s);
     // how many candidates each job accepted
     HSS_HIP(hipMemcpyAsync(hacc.data(), dnacc, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, s));
+    HSS_HIP(hipMemcpyAsync(hmax.data(), dmaxall, sizeof(double) * 2 * (size_t)nj, hipMemcpyDeviceToHost, s));
     HSS_HIP(hipStreamSynchronize(s));
     // Q[done : done+b', :] = LinvP * W, its conjugate transpose, and the rows of L against the earlier blocks (in accepted order)
     each([&](int a, QrJob<T>& J, St& S, int b) {
@@ -918,6 +1116,20 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       if (na > 0) subs.push_back(SubJob<T>{S.Q + S.done, S.ldq, nullptr, nullptr, 0, 0, na, J.q, S.Qh + (size_t)S.done * S.ldqh, S.ldqh, 2});
     });
     run_subs(tmp, subs, s);
+    {  // norm_select: coefficients of EVERY row against the rows accepted in this window, and the downdate of the residual norms
+      each([&](int a, QrJob<T>& J, St& S, int) {
+        const int na = hacc[a];
+        if (!J.norm_select || na <= 0) return;
+        g.push_back(GemmProb<T>{J.M, S.Qh + (size_t)S.done * S.ldqh, S.LRS + (size_t)S.done * S.ldr, J.m, na, J.q, J.ldm, S.ldqh, S.ldr});
+      });
+      run_gemms(tmp, g, 0, s);
+      each([&](int a, QrJob<T>& J, St& S, int) {
+        const int na = hacc[a];
+        if (!J.norm_select || na <= 0) return;
+        normjobs.push_back(NormJob<T>{S.LRS + (size_t)S.done * S.ldr, S.ldr, J.m, na, S.res2, 1, nullptr});
+      });
+      run_norms();
+    }
     HSS_HIP(hipStreamSynchronize(s));  // lperm / nacc are rewritten by the next window
     for (int a = 0; a < nj; ++a) {
       St& S = st[a];
@@ -935,6 +1147,37 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
       // accepts nothing ends the job
       if (S.done >= jobs[a].rmax || na == 0) S.active = 0;
       (void)b;
+    }
+    {  // norm_select: once the largest downdated norm^2 has fallen by 1e10 since the norms were last exact it has lost its digits: recompute
+       // every row's residual from M - L_RS * Q (one product with K = rows accepted so far; twice or so in a compression at 1e-12)
+      std::vector<int> fresh;
+      for (int a = 0; a < nj; ++a) {
+        St& S = st[a];
+        if (!S.active || !jobs[a].norm_select) continue;
+        if (S.refmax == 0.0) S.refmax = hmax[2 * a];
+        if (hmax[2 * a] < 1e-10 * S.refmax && S.done > 0) fresh.push_back(a);
+      }
+      if (!fresh.empty()) {
+        std::vector<T*> Rt(fresh.size(), nullptr);
+        std::vector<SubJob<T>> cp;
+        for (size_t f = 0; f < fresh.size(); ++f) {
+          const int a = fresh[f];
+          Rt[f] = tmp.get<T>((size_t)ev(jobs[a].m) * jobs[a].q);
+          cp.push_back(SubJob<T>{jobs[a].M, jobs[a].ldm, nullptr, nullptr, 0, 0, jobs[a].m, jobs[a].q, Rt[f], ev(jobs[a].m), 0});
+        }
+        run_subs(tmp, cp, s);
+        for (size_t f = 0; f < fresh.size(); ++f) {
+          const int a = fresh[f];
+          g.push_back(GemmProb<T>{st[a].LRS, st[a].Q, Rt[f], jobs[a].m, jobs[a].q, st[a].done, st[a].ldr, st[a].ldq, ev(jobs[a].m)});
+        }
+        run_gemms(tmp, g, 1, s);
+        for (size_t f = 0; f < fresh.size(); ++f) {
+          const int a = fresh[f];
+          normjobs.push_back(NormJob<T>{Rt[f], ev(jobs[a].m), jobs[a].m, jobs[a].q, st[a].res2, 0, nullptr});
+          st[a].refmax = hmax[2 * a];
+        }
+        run_norms();
+      }
     }
     // a rejected candidate above the threshold keeps the job going; one below it ends the job -- told apart by the next window: its first pivot is then <= tau
   }
@@ -973,8 +1216,12 @@ void qr_refine(Pool& tmp, Pool& out_pool, std::vector<QrJob<T>>& jobs, double at
     St& S = st[a];
     const int nR = J.m - J.r;
     if (nR <= 0 || J.r <= 0) continue;
-    YR[a] = tmp.get<T>((size_t)ev(nR) * J.q);
     T2[a] = tmp.get<T>((size_t)ev(nR) * HS_QW);
+    if (J.norm_select) {  // L_RS is already there, block column by block column: the rows of the redundant candidates
+      rows.push_back(RowJob<T>{S.LRS, S.ldr, J.Tm, J.ldt, J.p + J.r, nR, J.r, ROW_GATHER});
+      continue;
+    }
+    YR[a] = tmp.get<T>((size_t)ev(nR) * J.q);
     rows.push_back(RowJob<T>{J.M, J.ldm, YR[a], ev(nR), J.p + J.r, nR, J.q, ROW_GATHER});
     HSS_HIP(hipMemsetAsync(J.Tm, 0, sizeof(T) * (size_t)J.ldt * J.r, s));
     g.push_back(GemmProb<T>{YR[a], S.Qh, J.Tm, nR, J.r, J.q, ev(nR), S.ldqh, J.ldt});
@@ -1303,7 +1550,15 @@ bool compress_fixed(HssT<T>& H, std::vector<CBlock<T>>& cb, int k, BlockOp<T>* b
     // that couples weakly (or not at all) is noise of the children's truncation, and relative to ITSELF noise has full rank
     double gscale = 0.0;  // (the tolerance only matters to the LU-based rank rule, HS_HSS_QR=0: the largest scale of the batch)
     for (auto& B : cb) gscale = std::max(gscale, B.gscale);
-    const int st = lowrank_compress_batch<T>(jobs.data(), nj, std::max(std::max(H.opt.atol, H.opt.rtol * gscale) * lsc, noise_max), H.opt.rtol * lsc, s, false);
+    const bool norm_order = qr_norm_order();  // HS_QR_ORDER=norm: no pivoted LU of a sketch; qr_refine picks its windows by residual norms
+    std::vector<int*> porder(nj, nullptr);
+    int st = 0;
+    if (norm_order) {
+      for (int a = 0; a < nj; ++a) porder[a] = tmp.get<int>((size_t)std::max(nd[L[a]].m, 1));
+    } else {
+      st = lowrank_compress_batch<T>(jobs.data(), nj, std::max(std::max(H.opt.atol, H.opt.rtol * gscale) * lsc, noise_max), H.opt.rtol * lsc, s, false);
+      for (int a = 0; a < nj; ++a) porder[a] = lr[a].rperm;
+    }
     for (int a = 0; a < nj; ++a) cb[nblk[L[a]]].gscale = std::max(cb[nblk[L[a]]].gscale, lr[a].top);
     vlap("pivot order (tournament LU of sketches)", lv);
     auto free_lr = [&]() {
@@ -1324,8 +1579,9 @@ bool compress_fixed(HssT<T>& H, std::vector<CBlock<T>>& cb, int k, BlockOp<T>* b
         qj[a].ldm = ldl[i];
         qj[a].m = nd[i].m;
         qj[a].q = k2;
-        qj[a].p = lr[a].rperm;
-        qj[a].rmax = lr[a].k;  // the pivoted LU ordered the first k (sketch width) rows; the orthogonalisation stops by itself once a block of 32 rows is below the threshold
+        qj[a].p = porder[a];
+        qj[a].norm_select = norm_order;
+        qj[a].rmax = norm_order ? std::min(nd[i].m, k) : lr[a].k;  // the pivoted LU ordered the first k (sketch width) rows; the orthogonalisation stops by itself once a block of 32 rows is below the threshold
         qj[a].atol_scale = std::max(H.opt.atol, H.opt.rtol * cb[nblk[i]].gscale_q);  // absolute threshold of ITS matrix (times lsc below)
         qj[a].floor_abs = noise[nblk[i]];
       }
@@ -1377,7 +1633,7 @@ bool compress_fixed(HssT<T>& H, std::vector<CBlock<T>>& cb, int k, BlockOp<T>* b
         HNode<T>& x = nd[i];
         const int m = x.m, r = x.r, nR = m - r;
         x.p = H.keep.template get<int>(m);
-        HSS_HIP(hipMemcpyAsync(x.p, lr[a].rperm, sizeof(int) * m, hipMemcpyDeviceToDevice, s));
+        HSS_HIP(hipMemcpyAsync(x.p, porder[a], sizeof(int) * m, hipMemcpyDeviceToDevice, s));
         x.sk = H.keep.template get<int>(r);
         x.ldt = ev(nR);
         x.ldtt = ev(r);
@@ -2241,7 +2497,9 @@ int lowrank_id_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, h
     for (int pass = 0; !todo.empty(); ++pass) {
       auto t0 = std::chrono::steady_clock::now();
       // pivot order: tournament-pivoted LU of the sketches (its own rank estimate is not used: |u_jj| overestimates the residual norms)
-      int st = lowrank_compress_batch<T>(todo.data(), (int)todo.size(), atol, rtol, s, false, true);
+      // HS_QR_ORDER=norm: no pivoted LU -- the sketch alone, the windows of qr_refine chosen by downdated residual norms (a blocked column-pivoted QR)
+      const bool norm_order = qr_norm_order();
+      int st = lowrank_compress_batch<T>(todo.data(), (int)todo.size(), atol, rtol, s, false, true, norm_order);
       if (st != 0) return st;
       if (qtime) {
         (void)hipStreamSynchronize(s);
@@ -2260,6 +2518,7 @@ int lowrank_id_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, h
         q.q = o.k;
         q.p = o.rperm;
         q.rmax = o.k;
+        q.norm_select = norm_order;
         q.atol_scale = std::sqrt((double)o.k);  // the sketch is not normalised: |row of X*Omega| ~ sqrt(k) |row of X|
         qj.push_back(q);
         idx.push_back((int)a);

@@ -40,7 +40,7 @@ struct LowRankJob {
 template <class T>
 // need_z = false: only the pivoted LU of the sketch, the row permutation and the rank are wanted (the HSS module takes its
 // interpolation matrices from them): Z is not formed and X is left as it was
-int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z = true, bool keep_sketch = false);
+int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z = true, bool keep_sketch = false, bool sketch_only = false);  // sketch_only: Y0 = X * Omega and nothing else (the caller orders the rows itself: qr_refine with norm_select)
 // hs_hss.hip: the interpolative form X ~= C*Z with Z = r ROWS of X and C = P'[I; T] -- pivot order from the tournament-pivoted LU of the
 // sketch, rank (tolerance-stopped) and least-squares T from the windowed-pivoted orthogonalisation of the sketch rows (qr_refine): the role
 // of `pqrfact(X; atol, rtol)` (rank-revealing QR) in `_lgauss_transform` / `_rgauss_transform` (src/factorization.jl:171-182).  X is left

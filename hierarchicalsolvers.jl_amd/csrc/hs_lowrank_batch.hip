@@ -132,7 +132,7 @@ struct Guard {  // frees what it was given, whatever the exit path
   } while (0)
 
 template <class T>
-int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z, bool keep_sketch) {
+int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double rtol, hipStream_t s, bool need_z, bool keep_sketch, bool sketch_only) {
   std::vector<int> todo;
   for (int i = 0; i < njobs; ++i) {
     LowRankJob<T>& J = jobs[i];
@@ -297,6 +297,26 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
         hipLaunchKernelGGL(sparse_sketch_kernel<T>, dim3((unsigned)((smaxrows + 255) / 256), (unsigned)smaxk, (unsigned)sj.size()), dim3(256), 0, s, (const SparseSketchJob<T>*)dsj);
       }
     }
+    if (sketch_only) {  // no pivoted LU: the sketches themselves are the result (rows ordered by the caller)
+      for (int a = 0; a < nj; ++a) {
+        LowRankJob<T>& J = jobs[todo[a]];
+        LowRank<T>& o = *J.out;
+        if (hs_lr_alloc((void**)&o.rperm, sizeof(int) * (size_t)J.rows) != 0) {
+          free_Y();
+          hs_set_error(-7, 0, "hipMalloc of a row list (%d) failed", J.rows);
+          return -7;
+        }
+        o.Y0 = Y[a];
+        Y[a] = nullptr;
+        o.Lp = nullptr;
+        o.ldp = ldp[a];
+        o.k = J.k;
+        o.r = 0;
+        o.top = 0.0;
+      }
+      LRB_HIP(hipStreamSynchronize(s));
+      return 0;
+    }
     if (keep_sketch) {  // the orthogonalisation that refines rank and interpolation reads the sketch itself, not its L\U
       for (int a = 0; a < nj; ++a) {
         const LowRankJob<T>& J = jobs[todo[a]];
@@ -393,5 +413,5 @@ int lowrank_compress_batch(LowRankJob<T>* jobs, int njobs, double atol, double r
   return 0;
 }
 
-template int lowrank_compress_batch<double>(LowRankJob<double>*, int, double, double, hipStream_t, bool, bool);
-template int lowrank_compress_batch<cplx>(LowRankJob<cplx>*, int, double, double, hipStream_t, bool, bool);
+template int lowrank_compress_batch<double>(LowRankJob<double>*, int, double, double, hipStream_t, bool, bool, bool);
+template int lowrank_compress_batch<cplx>(LowRankJob<cplx>*, int, double, double, hipStream_t, bool, bool, bool);

@@ -323,6 +323,14 @@ def trim():
     return int(_lib.lib().hs_hss_trim())
 
 
+def qr_order(mode=None):
+    """Row order of the rank-revealing orthogonalisation inside every compression (``pqrfact``'s role, factorization.jl:171-182):
+    ``"lu"`` (default: tournament-pivoted LU order + windowed Cholesky-QR) or ``"norm"`` (blocked column-pivoted QR by downdated residual
+    norms: the greedy order itself, slower; include/hs_hss.h hs_hss_qr_order).  Returns the previous setting; ``None`` only reads."""
+    code = -1 if mode is None else {"lu": 0, "norm": 1}[mode]
+    return ("lu", "norm")[int(_lib.lib().hs_hss_qr_order(code))]
+
+
 def randcompress_adaptive(A, cl=None, *, kest=64, **kw):
     """``randcompress_adaptive(A, cl, cl; kest, atol, rtol)`` (factorization.jl:110): the compression IS randomized and
     adaptive (samples double until every rank fits); ``kest`` is the initial number of samples."""

@@ -123,6 +123,15 @@ int hs_hss_child(hs_hss* H, int which, hs_hss** out);
 int hs_hss_pack_size(const hs_hss* H, int64_t* bytes);
 int hs_hss_pack(hs_hss* H, void* dev_buf, int64_t bytes, void* stream);
 int hs_hss_unpack(const void* dev_buf, int64_t bytes, int is_complex, void* stream, hs_hss** out);
+/* Order in which the rank-revealing orthogonalisation inside every compression takes its rows (the role of `pqrfact`,
+ * src/factorization.jl:171-182, a column-pivoted QR stopped at the tolerance):
+ *   0 (default)  the pivot order of a tournament-pivoted LU of a sketch, then windowed pivoted Cholesky-QR with re-orthogonalisation
+ *   1            no LU: a blocked column-pivoted QR -- every window is the rows of largest residual norm (downdated, recomputed when they
+ *                have lost digits), and a pivot is accepted only while it is at least HS_QR_THETA (0.5) times every residual outside the
+ *                window: the greedy order of `pqrfact` up to that factor.  Same ranks and errors as 0 (tests/test_hss_gpu.py), 1.5-2x the
+ *                time of the compressions; it exists to check 0 against.
+ * mode < 0 only reads.  Returns the previous mode.  Process-wide; the environment variable HS_QR_ORDER=norm sets the initial value. */
+int hs_hss_qr_order(int mode);
 /* The off-diagonal blocks of the top-level split in low-rank form, A12 = C*Z (which = 0: C = U_1*B12 is n1 x r2, Z = U_2^T is r2 x n2) or
  * A21 = C*Z (which = 1: C = U_2*B21 is n2 x r1, Z = U_1^T is r1 x n1): the factors `Uint = generators(S.A11)[1]*S.B12`, `Vbnd` that a parent
  * front takes its low-rank couplings Aib, Abi from (src/factorization.jl:129-137).  Sizes and ranks: hs_hss_node_info of nodes 1 and 2. */

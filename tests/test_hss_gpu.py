@@ -456,3 +456,48 @@ def test_pack_unpack_roundtrip(hs, complex_):
         hs.hss.HssMatrix.unpack(bad, complex_)
     with pytest.raises(ValueError):
         hs.hss.HssMatrix.unpack(H.pack(), not complex_)
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_residual_norm_order_is_a_pivoted_qr_and_agrees_with_the_default(hs, complex_):
+    """hs_hss_qr_order(1): every window of the orthogonalisation is chosen by downdated residual norms and a pivot is accepted only while it is
+    >= 0.5 x every residual outside the window -- the greedy order of `pqrfact` (src/factorization.jl:171-182).  The default (tournament order)
+    must deliver the same ranks (+-3 % + 2) and the same errors (within 3x), from 1e-3 down to 1e-12; and the ranks of the greedy order are
+    within 6 % + 3 of the oracle's, whose IDs are scipy's column-pivoted QR stopped at the same tolerance."""
+    if complex_:  # points of a 2-D sheet (a separator) in recursive-bisection order, Helmholtz-like kernel: ranks grow like sqrt(n)
+        m = 36
+        gx, gy = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+        P = np.stack([gx.ravel(), gy.ravel()], 1).astype(float)
+
+        def rb(idx):
+            if len(idx) <= 16:
+                return list(idx)
+            c = P[idx]
+            o = np.argsort(c[:, int(np.argmax(c.max(0) - c.min(0)))], kind="stable")
+            h = len(idx) // 2
+            return rb(idx[o[:h]]) + rb(idx[o[h:]])
+
+        P = P[rb(np.arange(m * m))]
+        R = np.sqrt(((P[:, None, :] - P[None, :, :]) ** 2).sum(-1))
+        A = np.exp(1j * 0.7 * R) / (1.0 + R) + (4.0 + 1.0j) * np.eye(m * m)
+    else:
+        A = kernel_matrix(1500, False)
+    nA = np.linalg.norm(A)
+    assert hs.hss.qr_order() == "lu"
+    try:
+        for tol in (1e-3, 1e-6, 1e-9, 1e-12):
+            out = {}
+            for order in ("lu", "norm"):
+                hs.hss.qr_order(order)
+                H = hs.hss.compress(A, leafsize=64, atol=tol * 1e-3, rtol=tol, kest=64)
+                out[order] = (H.rank, np.linalg.norm(H.full() - A) / nA)
+            (r0, e0), (r1, e1) = out["lu"], out["norm"]
+            print(f"complex={complex_} tol={tol:g}: lu rank {r0} err {e0:.2e} | norm rank {r1} err {e1:.2e}")
+            assert abs(r0 - r1) <= 0.03 * r1 + 2, out
+            assert e0 <= 3 * e1 + 1e-14 and e1 <= 3 * e0 + 1e-14, out
+            assert e1 < 30 * tol + 1e-13, out
+            if tol >= 1e-9:
+                ro = HS.hssrank(HS.compress(A, leafsize=64, atol=tol * 1e-3, rtol=tol, kest=64, level_scale=0.5))
+                assert abs(r1 - ro) <= 0.06 * ro + 3, (r1, ro)
+    finally:
+        hs.hss.qr_order("lu")

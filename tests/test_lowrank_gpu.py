@@ -76,3 +76,26 @@ def test_lowrank_exact_rank_and_full_rank(hs):
     Zr = np.zeros((60, 50))
     r, Cm, Z = compress(hs, Zr, 1e-8, 1e-8)
     assert r == 0
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_lowrank_residual_norm_order_against_pivoted_qr(hs, cplx):
+    """The blocked column-pivoted QR order (hs_hss_qr_order(1), include/hs_hss.h) on one block: rank within 5 % + 2 of scipy's pivoted QR at the
+    same threshold (the default order is allowed 15 % + 4 above), same error level."""
+    import scipy.linalg as sla
+
+    X = kernel_matrix(1000, 777, cplx, seed=11)
+    d = np.abs(np.diag(sla.qr(X.conj().T, mode="r", pivoting=True)[0]))
+    s0 = np.linalg.norm(X, 2)
+    try:
+        for rtol in (1e-2, 1e-6, 1e-10):
+            r_qr = int(np.sum(d > rtol * d[0]))
+            hs.hss.qr_order("norm")
+            r, Cm, Z = compress(hs, X, 0.0, rtol)
+            err = np.linalg.norm(X - Cm @ Z, 2) / s0
+            print(f"cplx={cplx} rtol={rtol:g}: rank {r} (pivoted QR {r_qr}) err {err:.2e} max|C| {np.max(np.abs(Cm)):.2f}")
+            assert abs(r - r_qr) <= 0.05 * r_qr + 2, (r, r_qr)
+            assert err < 50 * rtol
+            assert np.max(np.abs(Cm)) < 8.0  # (a pivoted QR bounds |T| by 2^(r-j) only; in practice O(1) / theta)
+    finally:
+        hs.hss.qr_order("lu")
