@@ -82,7 +82,7 @@ EXPORTS = [
     "hs_hss_options_default", "hs_hss_compress_d", "hs_hss_compress_z", "hs_hss_compress_ex_d", "hs_hss_compress_ex_z", "hs_hss_compress_lru_d", "hs_hss_compress_lru_z", "hs_hss_compress_lru_multi_d", "hs_hss_compress_lru_multi_z", "hs_hss_set_stream", "hs_hss_rank", "hs_hss_size", "hs_hss_samples", "hs_hss_num_nodes",
     "hs_hss_node_info", "hs_hss_node_data", "hs_hss_getindex", "hs_hss_basis", "hs_hss_expand", "hs_hss_mul", "hs_hss_mul_t", "hs_hss_child", "hs_hss_factor", "hs_hss_ldiv", "hs_hss_time", "hs_hss_trim", "hs_hss_free", "hs_node_schur_hss",
     "hs_hss_offdiag", "hs_hss_bytes", "hs_hss_prune_leaves", "hs_hss_compatible", "hs_hss_depth", "hs_hss_compress_blockop_d", "hs_hss_compress_blockop_z", "hs_hss_blockop_apply",
-    "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_mfma_f64_peak_random", "hsk_bisect_perm",
+    "hsk_gemm_d", "hsk_gemm_z", "hsk_lowrank_d", "hsk_lowrank_z", "hsk_front_factor_d", "hsk_front_factor_z", "hsk_mfma_f64_peak", "hsk_mfma_f64_peak_random", "hsk_flow_pingpong_us", "hsk_bisect_perm",
     "hs_probs_stats_mode", "hs_probs_stats", "hs_trim", "hs_stream_order",
 ]
 
@@ -310,6 +310,8 @@ def lib():
     L.hs_probs_stats_mode.restype = C.c_int
     L.hs_probs_stats.argtypes = [p_f64]
     L.hs_probs_stats.restype = C.c_int
+    L.hsk_flow_pingpong_us.argtypes = [C.c_int, C.c_int]
+    L.hsk_flow_pingpong_us.restype = C.c_double
     L.hsk_mfma_f64_peak.argtypes = [C.c_int, C.c_int]
     L.hsk_mfma_f64_peak.restype = C.c_double
     L.hsk_mfma_f64_peak_random.argtypes = [C.c_int, C.c_int]

@@ -241,6 +241,12 @@ struct hs_handle {
   void* d_solve = nullptr;  // SolveNode<T>[] (same order as d_nodes)
   void* d_w1 = nullptr;
   void* d_w2 = nullptr;
+  int* d_flow = nullptr;    // dataflow sweeps (kernels_solve_wide.hip): 64 workgroup-id counters, one per launch, used as a ring
+  void* d_e1 = nullptr;     // ... the exchange vectors (laid out like d_w1): y / x, and the finished w of the diagonal blocks
+  void* d_e2 = nullptr;
+  size_t flow_bytes = 0;
+  int* h_flow_err = nullptr;  // pinned, device-visible: raised by a sweep workgroup whose bounded wait ran out
+  int flow_seq = 0;
   void* d_part = nullptr;
   void* d_b = nullptr;
   size_t fac_elems = 0, inv_elems = 0, sb_elems = 0, int_elems = 0;
@@ -366,6 +372,10 @@ static void free_handle(hs_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->d_gflags) (void)hipFree(h->d_gflags);
+  if (h->d_flow) (void)hipFree(h->d_flow);
+  if (h->d_e1) (void)hipFree(h->d_e1);
+  if (h->d_e2) (void)hipFree(h->d_e2);
+  if (h->h_flow_err) (void)hipHostFree(h->h_flow_err);
   for (void* q : {h->d_xs, h->d_xr, h->d_xall, (void*)h->d_owned_all})
     if (q) (void)hipFree(q);
   if (h->ev_ca) (void)hipEventDestroy(h->ev_ca);
@@ -1098,6 +1108,13 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
     lapa("descriptors");
     dmalloc(&h->d_w1, (size_t)(woff + 1) * sizeof(T), "solve workspace");
     dmalloc(&h->d_w2, (size_t)(woff + 1) * sizeof(T), "solve workspace");
+    dmalloc((void**)&h->d_flow, 64 * sizeof(int), "sweep counters");
+    HS_HIP(hipMemset(h->d_flow, 0, 64 * sizeof(int)));
+    h->flow_bytes = (size_t)(woff + 1) * sizeof(T);
+    dmalloc(&h->d_e1, h->flow_bytes, "sweep exchange vector");
+    dmalloc(&h->d_e2, h->flow_bytes, "sweep exchange vector");
+    HS_HIP(hipHostMalloc((void**)&h->h_flow_err, sizeof(int), hipHostMallocMapped));
+    *h->h_flow_err = 0;
     dmalloc(&h->d_part, (size_t)(poff + 1) * sizeof(T), "solve partial sums");
     dmalloc(&h->d_b, (size_t)n * sizeof(T), "right-hand side");
 
@@ -1353,8 +1370,33 @@ static void numeric_end(hs_handle* h) {
 // ------------------------------------------------------------------------------------------------
 // ldiv!
 // ------------------------------------------------------------------------------------------------
+// dataflow sweeps (kernels_solve_wide.hip): HS_SOLVE_FLOW=0 goes back to one launch per 256 columns
+static bool solve_flow_on() {
+  static const bool on = !(getenv("HS_SOLVE_FLOW") && getenv("HS_SOLVE_FLOW")[0] == '0');
+  return on;
+}
+// the workgroup-id counter of the next sweep launch: a ring of 64, cleared (in stream order) every time it wraps
+static int* flow_counter(hs_handle* h, hipStream_t s) {
+  const int slot = h->flow_seq++ % 64;
+  if (slot == 0) HS_HIP(hipMemsetAsync(h->d_flow, 0, 64 * sizeof(int), s));
+  return h->d_flow + slot;
+}
+// the exchange vectors hold the sentinel (all bits set) wherever nothing has been published yet: once per sweep direction, every level of
+// the sweep has its own range of them
+static void flow_arm(hs_handle* h, hipStream_t s) {
+  if (!solve_flow_on() || !h->d_e1) return;
+  HS_HIP(hipMemsetAsync(h->d_e1, 0xFF, h->flow_bytes, s));
+  HS_HIP(hipMemsetAsync(h->d_e2, 0xFF, h->flow_bytes, s));
+}
+static void flow_check(hs_handle* h) {
+  if (h->h_flow_err && *h->h_flow_err) {
+    *h->h_flow_err = 0;
+    HS_FAIL(HS_ERR_DEVICE, 0, "ldiv!: a sweep workgroup waited for a block that never arrived (dataflow sweeps; HS_SOLVE_FLOW=0 selects the launch-per-step sweeps)");
+  }
+}
 template <class T>
 static void solve_fwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s) {
+  flow_arm(h, s);
   const SolveNode<T>* sn = (const SolveNode<T>*)h->d_solve;
   T* w1 = (T*)h->d_w1;
   T* w2 = (T*)h->d_w2;
@@ -1368,7 +1410,9 @@ static void solve_fwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
     const int nb_ = (int)L.mine.size();
     launch_fwd_gather<T>(dn, nb_, L.maxni, db, w1, s);
     static const bool wide = !(getenv("HS_SOLVE_WIDE") && getenv("HS_SOLVE_WIDE")[0] == '0');  // 256 columns per launch (kernels_solve_wide.hip)
-    if (wide) {
+    if (solve_flow_on()) {  // the whole level in one launch
+      launch_fwd_flow<T>(dn, nb_, L.maxni, L.maxnb, w1, w2, db, (T*)h->d_e1, (T*)h->d_e2, flow_counter(h, s), h->h_flow_err, s);
+    } else if (wide) {
       const int nblk = (L.maxni + hs_solve_wide_cols() - 1) / hs_solve_wide_cols();
       for (int blk = 0; blk < nblk; ++blk) launch_fwd_wide<T>(dn, nb_, blk, L.maxm, w1, w2, db, s);
     } else {
@@ -1381,6 +1425,7 @@ static void solve_fwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
 }
 template <class T>
 static void solve_bwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s) {
+  flow_arm(h, s);
   const SolveNode<T>* sn = (const SolveNode<T>*)h->d_solve;
   T* w1 = (T*)h->d_w1;
   T* w2 = (T*)h->d_w2;
@@ -1397,7 +1442,9 @@ static void solve_bwd(hs_handle* h, T* db, int lv_from, int lv_to, hipStream_t s
     solve_lr_bwd<T>(h, lv, db, s);
     const int nblk = (L.maxni + HS_PB - 1) / HS_PB;
     static const bool wide = !(getenv("HS_SOLVE_WIDE") && getenv("HS_SOLVE_WIDE")[0] == '0');
-    if (wide) {
+    if (solve_flow_on()) {
+      launch_bwd_flow<T>(dn, nb_, L.maxni, w1, w2, (T*)h->d_e1, (T*)h->d_e2, flow_counter(h, s), h->h_flow_err, s);
+    } else if (wide) {
       const int nw = (L.maxni + hs_solve_wide_cols() - 1) / hs_solve_wide_cols();
       for (int blk = nw - 1; blk >= 0; --blk) launch_bwd_wide<T>(dn, nb_, blk, w1, w2, s, blk == nw - 1);
     } else {
@@ -1456,8 +1503,9 @@ static void solve_dist(hs_handle* h, T* db, hipStream_t s) {
   launch_unpack_idx(h->d_owned_all, (int)off[h->nranks], db, all, esz, s);
 }
 
-static void check_solve_args(const hs_handle* h, bool cplx, int64_t ldc, int64_t ldb, int64_t n, int64_t nrhs) {
+static void check_solve_args(hs_handle* h, bool cplx, int64_t ldc, int64_t ldb, int64_t n, int64_t nrhs) {
   check_handle(h);
+  flow_check(h);
   if (!h->factored) HS_FAIL(HS_ERR_ARGUMENT, 0, "ArgumentError: factorization is not complete");
   if (h->is_complex != cplx) HS_FAIL(HS_ERR_ARGUMENT, 0, "MethodError: eltype of F and B differ");
   if (n != h->n || ldc < n || ldb < n || nrhs < 0)
@@ -1485,6 +1533,7 @@ static void ldiv_host(hs_handle* h, T* C, int64_t ldc, const T* B, int64_t ldb, 
     HS_HIP(hipEventRecord(h->ev1, s));
     HS_HIP(hipMemcpyAsync(C + r * ldc, db, n * sizeof(T), hipMemcpyDeviceToHost, s));
     HS_HIP(hipStreamSynchronize(s));
+    flow_check(h);
     float ms = 0.f;
     HS_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     tsum += ms * 1e-3;

@@ -250,6 +250,12 @@ void launch_bwd_wide(const SolveNode<T>* dn, int nbatch, int blk, T* w, T* x, hi
 template <class T>
 void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s, int only_block = -1);
 int hs_solve_wide_cols();
+// the sweeps of a whole level in ONE launch (dataflow over published values; kernels_solve_wide.hip).  E1, E2: exchange vectors laid out like w,
+// filled with 0xFF bytes (the sentinel) before the launch
+template <class T>
+void launch_fwd_flow(const SolveNode<T>* dn, int nbatch, int maxni, int maxnb, T* w, T* y, T* b, T* E1, T* E2, int* counter, int* err, hipStream_t s);
+template <class T>
+void launch_bwd_flow(const SolveNode<T>* dn, int nbatch, int maxni, T* w, T* x, T* E1, T* E2, int* counter, int* err, hipStream_t s);
 template <class T>
 void launch_bwd_scatter(const SolveNode<T>* dn, int nbatch, int maxni, T* b, const T* x, hipStream_t s);
 

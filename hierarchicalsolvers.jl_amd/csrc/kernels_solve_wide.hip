@@ -306,6 +306,300 @@ __global__ __launch_bounds__(1024) void wide_first_kernel(const SolveNode<T>* __
   if (t < wl) out[nd.woff + c0 + t] = wide_sum<T>(s_red, t);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dataflow sweeps (round 3): ONE launch per tree level and sweep instead of ni/256 dependent launches per front.
+//
+// The launch-per-step sweeps above cost 18-24 us per 256 columns whatever the panel size (307 steps per sweep at Poisson 128^3), and a
+// step is a chain of two dependent 256 x 256 tile products by ONE workgroup (512 KB each: ~6 us) between memory round trips.  Here
+//  * a workgroup of 256 threads OWNS 64 rows of a front for the whole sweep: it accumulates sum_k L[rows, blk k] * y_k in registers as
+//    the y_k arrive, so the tile on the chain is 64 x 256 (128 KB), and four workgroups share what one did per step;
+//  * values are exchanged through two vectors that hold a SENTINEL (all bits set: no arithmetic produces that NaN) until the value is
+//    published with an agent-scope atomic store; a consumer polls the values themselves with agent-scope atomic loads -- no flag, no
+//    fence, one memory round trip per exchange.  E1 carries y (x in the backward sweep), E2 the finished w of a diagonal block: the rows
+//    q*64.. of y_j = inv256_j * w_j need w of the sub-blocks <= q (>= q backward), so a 256-step is tile -> w -> inverse slab -> y;
+//  * forward progress: a workgroup waits only for sub-blocks of the SAME front that come earlier in the sweep, and workgroup ids are
+//    handed out by an atomic counter in the order the workgroups actually start (block-major, front-minor: all fronts of a level advance
+//    together), so everything a workgroup waits for has started.  Every poll is bounded (HS_FLOW_SPIN rounds of s_sleep, seconds): a
+//    workgroup that runs out raises *err and leaves without publishing, its dependents run out in turn, the grid drains, and the host
+//    reports it at the next call instead of the GPU hanging.
+// ------------------------------------------------------------------------------------------------
+#define HS_FLOW_SPIN (1 << 22)
+#define HS_FB 64  // rows a workgroup owns
+static constexpr unsigned long long HS_SENT = ~0ull;
+
+template <class T>
+struct FlowCfg {
+  static constexpr int RP = sizeof(T) == 8 ? 2 : 1;  // rows per thread
+  static constexpr int RT = HS_FB / RP;               // threads along the rows
+  static constexpr int NG = 256 / RT;                 // column groups (8 real, 4 complex)
+  static constexpr int GC = HS_SW / NG;               // columns per group
+};
+__device__ __forceinline__ unsigned long long flow_ldbits(const double* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flow_publish(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flow_publish(cplx* p, cplx v) {
+  flow_publish(reinterpret_cast<double*>(p), v.re);
+  flow_publish(reinterpret_cast<double*>(p) + 1, v.im);
+}
+// thread t (of 256) fetches element t of a published vector (cnt <= 256 entries) into dst[t], zero beyond cnt; false when the wait ran out
+__device__ __forceinline__ bool flow_poll(const double* src, int cnt, double* dst, int t) {
+  if (t >= cnt) {
+    dst[t] = 0.0;
+    return true;
+  }
+  for (int it = 0; it < HS_FLOW_SPIN; ++it) {
+    const unsigned long long v = flow_ldbits(src + t);
+    if (v != HS_SENT) {
+      dst[t] = __longlong_as_double((long long)v);
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+__device__ __forceinline__ bool flow_poll(const cplx* src, int cnt, cplx* dst, int t) {
+  if (t >= cnt) {
+    dst[t] = cplx{0.0, 0.0};
+    return true;
+  }
+  const double* q = reinterpret_cast<const double*>(src + t);
+  for (int it = 0; it < HS_FLOW_SPIN; ++it) {
+    const unsigned long long a = flow_ldbits(q), b = flow_ldbits(q + 1);
+    if (a != HS_SENT && b != HS_SENT) {
+      dst[t] = cplx{__longlong_as_double((long long)a), __longlong_as_double((long long)b)};
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+// s[0..RP) += A[rows of the thread, columns of its group within [c_lo, c_hi)] * sv[...]; `a` points at (first row of the workgroup, column 0 of the block)
+template <class T>
+__device__ __forceinline__ void flow_dot(const T* a, size_t ld, int c_lo, int c_hi, const T* sv, int rl, int t, T* s) {
+  constexpr int RP = FlowCfg<T>::RP, RT = FlowCfg<T>::RT, GC = FlowCfg<T>::GC;
+  const int row = (t % RT) * RP, jg = (t / RT) * GC;
+  const int jlo = max(jg, c_lo), jhi = min(jg + GC, c_hi), nrows = min(RP, rl - row);
+  if (jlo == jg && jhi == jg + GC && nrows == RP) {
+    // a full group: every load of the thread issued before the first use -- ONE memory round trip for the tile (the generic loop below goes in
+    // batches of 16 loads: two dependent round trips on a chain where the round trip is what a step costs)
+    const T* p = a + row + (size_t)jg * ld;
+    if constexpr (RP == 2) {
+      hs_d2u v[GC];
+#pragma unroll
+      for (int j = 0; j < GC; ++j) v[j] = gld2(p + (size_t)j * ld);
+#pragma unroll
+      for (int j = 0; j < GC; ++j) {
+        const T y = sv[jg + j];
+        s[0] = Scal<T>::fma(v[j].x, y, s[0]);
+        s[1] = Scal<T>::fma(v[j].y, y, s[1]);
+      }
+    } else {
+      T v[GC];
+#pragma unroll
+      for (int j = 0; j < GC; ++j) v[j] = gld(p + (size_t)j * ld);
+#pragma unroll
+      for (int j = 0; j < GC; ++j) s[0] = Scal<T>::fma(v[j], sv[jg + j], s[0]);
+    }
+    return;
+  }
+  wide_dot<T>(a + row, ld, jlo, jhi, sv, nrows, s);
+}
+template <class T>
+__device__ __forceinline__ void flow_put(T* s_red, int t, const T* s) {
+  constexpr int RP = FlowCfg<T>::RP, RT = FlowCfg<T>::RT;
+  const int row = (t % RT) * RP, g = t / RT;
+#pragma unroll
+  for (int q = 0; q < RP; ++q) s_red[g * HS_FB + row + q] = s[q];
+}
+template <class T>
+__device__ __forceinline__ T flow_sum(const T* s_red, int t) {  // t < HS_FB
+  T v = s_red[t];
+#pragma unroll
+  for (int g = 1; g < FlowCfg<T>::NG; ++g) v = v + s_red[g * HS_FB + t];
+  return v;
+}
+
+// One sweep of one level.  UPPER = false: forward (L below the diagonal, rows down to mrows: the Abi*U^-1 rows update rhs[bnd]);
+// UPPER = true: backward (U above the diagonal).  w: the level's work vector (in: gathered / updated right-hand side), out: y (x).
+template <class T, bool UPPER>
+__global__ __launch_bounds__(256) void flow_sweep_kernel(const SolveNode<T>* __restrict__ nodes, int nbatch, T* __restrict__ w, T* __restrict__ out,
+                                                         T* __restrict__ b, T* __restrict__ E1, T* __restrict__ E2, int* __restrict__ counter,
+                                                         int* __restrict__ err) {
+  __shared__ int s_id;
+  __shared__ T s_v[HS_SW];
+  __shared__ T s_red[HS_FB * FlowCfg<T>::NG];
+  const int t = threadIdx.x;
+  if (t == 0) s_id = atomicAdd(counter, 1);
+  __syncthreads();
+  const int id = s_id, f = id % nbatch, sb = id / nbatch;
+  const SolveNode<T> nd = nodes[f];
+  if (nd.ni <= 0) return;
+  const int ncb = (nd.ni + HS_SW - 1) / HS_SW;
+  constexpr int Q = HS_SW / HS_FB;  // sub-blocks per 256-block
+  int jb, q, rs, rl;
+  bool interior;
+  if (!UPPER) {
+    interior = sb < Q * ncb;
+    if (interior) {
+      jb = sb / Q;
+      q = sb % Q;
+      rs = jb * HS_SW + q * HS_FB;
+      rl = min(HS_FB, nd.ni - rs);
+    } else {
+      jb = ncb;  // all column blocks
+      q = 0;
+      rs = nd.ni + (sb - Q * ncb) * HS_FB;
+      rl = min(HS_FB, nd.mrows - rs);
+    }
+  } else {
+    interior = true;
+    if (sb >= Q * ncb) return;
+    jb = ncb - 1 - sb / Q;
+    q = Q - 1 - sb % Q;
+    rs = jb * HS_SW + q * HS_FB;
+    rl = min(HS_FB, nd.ni - rs);
+  }
+  if (rl <= 0) return;
+  T wold = Scal<T>::zero();
+  int gi = 0;
+  if (t < rl) {  // ahead of the tiles
+    if (interior) {
+      wold = w[nd.woff + rs + t];
+    } else {
+      gi = gld(nd.fidx + rs + t);
+      wold = b[gi];
+    }
+  }
+  constexpr int RP = FlowCfg<T>::RP;
+  T s[RP] = {};
+  const T* arow = nd.LF + (size_t)rs;
+  const int kfirst = UPPER ? ncb - 1 : 0, kstep = UPPER ? -1 : 1, kcount = UPPER ? ncb - 1 - jb : jb;
+  for (int c = 0, k = kfirst; c < kcount; ++c, k += kstep) {
+    const int wl = min(HS_SW, nd.ni - k * HS_SW);
+    const bool ok = flow_poll(E1 + nd.woff + (size_t)k * HS_SW, wl, s_v, t);
+    if (__syncthreads_or(ok ? 0 : 1)) {  // (also publishes s_v to the workgroup)
+      if (t == 0) *(volatile int*)err = 1;  // pinned host memory: a plain store
+      return;
+    }
+#ifdef HS_FLOW_EXPERIMENT_NOBULK  // timing experiment only (wrong results): tiles off the chain are not loaded
+    if (c + 1 >= kcount)
+#endif
+    flow_dot<T>(arow + (size_t)k * HS_SW * nd.ldl, nd.ldl, 0, wl, s_v, rl, t, s);
+    __syncthreads();  // s_v is refilled by the next round
+  }
+  flow_put<T>(s_red, t, s);
+  __syncthreads();
+  T wfin = Scal<T>::zero();
+  if (t < rl) wfin = wold - flow_sum<T>(s_red, t);
+  if (!interior) {
+    if (t < rl) b[gi] = wfin;
+    return;
+  }
+  // the diagonal block: publish the finished w of these rows, fetch the sub-blocks the inverse needs, multiply by the slab of the stored inverse
+  if (t < rl) flow_publish(E2 + nd.woff + rs + t, wfin);
+  const int wlj = min(HS_SW, nd.ni - jb * HS_SW);
+  const int c_lo = UPPER ? q * HS_FB : 0, c_hi = UPPER ? wlj : min(wlj, (q + 1) * HS_FB);
+  bool ok = true;
+  {
+    const int own_lo = q * HS_FB;
+    const bool own = t >= own_lo && t < own_lo + HS_FB;
+    if (!own) {
+      if (t >= c_lo && t < c_hi)
+        ok = flow_poll(E2 + nd.woff + (size_t)jb * HS_SW, c_hi, s_v, t);  // element t of the block's finished w
+      else
+        s_v[t] = Scal<T>::zero();
+    }
+    if (t < HS_FB) s_v[own_lo + t] = wfin;  // own rows: no round trip (zero beyond rl)
+  }
+  if (__syncthreads_or(ok ? 0 : 1)) {
+    if (t == 0) *(volatile int*)err = 1;
+    return;
+  }
+  {
+    T s2[RP] = {};
+    const T* inv = (UPPER ? nd.inv256U : nd.inv256L) + (size_t)jb * HS_SW * HS_SW + (size_t)(q * HS_FB);
+    flow_dot<T>(inv, HS_SW, c_lo, c_hi, s_v, rl, t, s2);
+    flow_put<T>(s_red, t, s2);
+  }
+  __syncthreads();
+  if (t < rl) {
+    const T v = flow_sum<T>(s_red, t);
+    flow_publish(E1 + nd.woff + rs + t, v);
+    out[nd.woff + rs + t] = v;
+    if (!UPPER) w[nd.woff + rs + t] = wfin;  // (what the launch-per-step sweep leaves behind: nothing reads it, kept for identical buffers)
+  }
+}
+
+template <class T>
+void launch_fwd_flow(const SolveNode<T>* dn, int nbatch, int maxni, int maxnb, T* w, T* y, T* b, T* E1, T* E2, int* counter, int* err, hipStream_t s) {
+  if (nbatch <= 0 || maxni <= 0) return;
+  const int nsb = (HS_SW / HS_FB) * ((maxni + HS_SW - 1) / HS_SW) + (std::max(maxnb, 0) + HS_FB - 1) / HS_FB;
+  hipLaunchKernelGGL((flow_sweep_kernel<T, false>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(256), 0, s, dn, nbatch, w, y, b, E1, E2, counter, err);
+}
+template <class T>
+void launch_bwd_flow(const SolveNode<T>* dn, int nbatch, int maxni, T* w, T* x, T* E1, T* E2, int* counter, int* err, hipStream_t s) {
+  if (nbatch <= 0 || maxni <= 0) return;
+  const int nsb = (HS_SW / HS_FB) * ((maxni + HS_SW - 1) / HS_SW);
+  hipLaunchKernelGGL((flow_sweep_kernel<T, true>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(256), 0, s, dn, nbatch, w, x, (T*)nullptr, E1, E2, counter, err);
+}
+template void launch_fwd_flow<double>(const SolveNode<double>*, int, int, int, double*, double*, double*, double*, double*, int*, int*, hipStream_t);
+template void launch_fwd_flow<cplx>(const SolveNode<cplx>*, int, int, int, cplx*, cplx*, cplx*, cplx*, cplx*, int*, int*, hipStream_t);
+template void launch_bwd_flow<double>(const SolveNode<double>*, int, int, double*, double*, double*, double*, int*, int*, hipStream_t);
+template void launch_bwd_flow<cplx>(const SolveNode<cplx>*, int, int, cplx*, cplx*, cplx*, cplx*, int*, int*, hipStream_t);
+
+// Latency of ONE exchange of the dataflow sweeps, measured: workgroup 0 publishes a counter value, workgroup `peer` answers it; `iters`
+// round trips with the publish / poll primitives above.  peer = 1: the next workgroup of the grid (another XCD: the hardware deals
+// workgroups round-robin over the 8 XCDs), peer = 8: the same XCD, another CU.  Every poll is bounded.
+__global__ __launch_bounds__(64) void flow_pingpong_kernel(double* A, double* B, int peer, int iters) {
+  if ((int)blockIdx.x != 0 && (int)blockIdx.x != peer) return;
+  if (threadIdx.x != 0) return;
+  const bool first = blockIdx.x == 0;
+  for (int i = 1; i <= iters; ++i) {
+    const unsigned long long want = (unsigned long long)__double_as_longlong((double)i);
+    if (first) {
+      flow_publish(A, (double)i);
+      int it = 0;
+      while (flow_ldbits(B) != want && ++it < HS_FLOW_SPIN) __builtin_amdgcn_s_sleep(1);
+      if (it >= HS_FLOW_SPIN) return;
+    } else {
+      int it = 0;
+      while (flow_ldbits(A) != want && ++it < HS_FLOW_SPIN) __builtin_amdgcn_s_sleep(1);
+      if (it >= HS_FLOW_SPIN) return;
+      flow_publish(B, (double)i);
+    }
+  }
+}
+extern "C" double hsk_flow_pingpong_us(int peer, int iters) {
+  double* d = nullptr;
+  if (peer < 1 || iters < 1 || hipMalloc((void**)&d, 4096) != hipSuccess) return -1.0;
+  (void)hipMemset(d, 0, 4096);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float ms = 0.f, ms1 = 0.f;
+  for (int rep = 0; rep < 2; ++rep) {  // the second pair is the measurement: (iters) against (1) round trips, so the launch itself cancels
+    (void)hipMemset(d, 0, 4096);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(flow_pingpong_kernel, dim3(peer + 1), dim3(64), 0, 0, d, d + 256, peer, iters);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipMemset(d, 0, 4096);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(flow_pingpong_kernel, dim3(peer + 1), dim3(64), 0, 0, d, d + 256, peer, 1);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms1, e0, e1);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d);
+  return iters > 1 ? (double)(ms - ms1) * 1e3 / (iters - 1) : (double)ms * 1e3;
+}
+
 template <class T>
 void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s, int only_block) {
   if (nbatch <= 0 || maxni <= 0) return;

@@ -53,6 +53,9 @@ int hsk_bisect_perm(int64_t n, const int64_t* colptr, const int64_t* rowval, int
 int hs_probs_stats_mode(int mode);
 int hs_probs_stats(double* out3);
 
+/* Microseconds per ROUND TRIP (two exchanges) between workgroup 0 and workgroup `peer` of one launch through agent-scope atomic stores and polled
+ * loads -- the exchange primitive of the dataflow sweeps of ldiv! (kernels_solve_wide.hip).  peer = 1: another XCD, peer = 8: the same XCD. */
+double hsk_flow_pingpong_us(int peer, int iters);
 /* Measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on every CU (roofline denominator). */
 double hsk_mfma_f64_peak(int waves_per_simd, int iters);
 /* The same issue loop on random operands that change while it runs: the rate at the clock the chip holds under such data (DVFS). */

@@ -295,3 +295,36 @@ def test_arena_cache_reuse_and_trim(hs):
     assert np.linalg.norm(P2["A"] @ x2 - P2["b"]) <= 1e-10 * np.linalg.norm(P2["b"])
     F2.free()
     hs.trim()
+
+
+@pytest.mark.parametrize("kind,shape,nmax", [("poisson", (40, 36, 33), 1400), ("helmholtz", (37, 30, 26), 900)])
+def test_dataflow_sweeps_agree_with_the_launch_per_step_sweeps(hs, kind, shape, nmax, tmp_path):
+    """ldiv! runs its triangular sweeps as ONE dataflow launch per level (kernels_solve_wide.hip: workgroups own 64 rows, values are exchanged
+    through sentinel-armed vectors); HS_SOLVE_FLOW=0 (read once per process: a child process) selects the launch-per-256-columns sweeps.  Both
+    must give the solution of SuperLU, ragged fronts (ni not a multiple of 64 or 256), several right-hand sides and repeated solves included."""
+    import subprocess
+    import sys
+
+    P = prepare(hs, shape, kind=kind, nmax=nmax, rhs="randn")
+    F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0)
+    rng = np.random.default_rng(2)
+    B = rng.standard_normal((len(P["b"]), 3)) + (1j * rng.standard_normal((len(P["b"]), 3)) if kind == "helmholtz" else 0)
+    ref = spla.splu(P["A"]).solve(B)
+    for rep in range(3):  # the exchange vectors are re-armed by every sweep
+        X = hs.ldiv(F, B)
+        assert relerr(X, ref) < SOL_TOL
+    np.save(tmp_path / "B.npy", B)
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {str(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))!r}); sys.path.insert(0, {str(os.path.dirname(os.path.abspath(__file__)))!r})
+import hsamd
+from helpers import prepare
+hs = hsamd.load()
+P = prepare(hs, {shape!r}, kind={kind!r}, nmax={nmax}, rhs="randn")
+F = hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0)
+np.save({str(tmp_path / "X0.npy")!r}, hs.ldiv(F, np.load({str(tmp_path / "B.npy")!r})))
+"""
+    env = dict(os.environ, HS_SOLVE_FLOW="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    X0 = np.load(tmp_path / "X0.npy")
+    assert relerr(X0, ref) < SOL_TOL and relerr(X, X0) < 1e-11
