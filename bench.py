@@ -424,6 +424,36 @@ def main():
             S.solve(b_dev)
         sync()
         t_ldiv = (time.perf_counter() - t0) / 3
+    # ... and once more level by level (hs_solve_*_levels with events between the levels): GB/s of the sweeps of every tree level against the
+    # bytes they must read, (ni^2 + 2 ni nb) * sizeof(T) per front
+    solve_levels = None
+    if world == 1 and not fopts.get("dist_top"):
+        try:
+            nl = S.plan.nlevels
+            st0 = S.stats()
+            lev_bytes = {}
+            import ctypes as _C
+
+            for node in range(int(st0["nnodes"])):
+                ni, nb, lv = _C.c_int64(), _C.c_int64(), _C.c_int64()
+                hs._lib.check(S.backend.L.hs_node_info(S.backend._h, node, _C.byref(ni), _C.byref(nb), _C.byref(lv)))
+                lev_bytes[lv.value] = lev_bytes.get(lv.value, 0) + (ni.value * ni.value + 2 * ni.value * nb.value) * (16 if is_c else 8)
+            b_dev.copy_(b_dev0)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nl + 1)]
+            evs[0].record()
+            for i, lv in enumerate(range(nl, 0, -1)):
+                S.backend.fwd(b_dev, lv, lv)
+                evs[i + 1].record()
+            for i, lv in enumerate(range(1, nl + 1)):
+                S.backend.bwd(b_dev, lv, lv)
+                evs[nl + i + 1].record()
+            sync()
+            fw = {lv: evs[i].elapsed_time(evs[i + 1]) for i, lv in enumerate(range(nl, 0, -1))}
+            bw = {lv: evs[nl + i].elapsed_time(evs[nl + i + 1]) for i, lv in enumerate(range(1, nl + 1))}
+            solve_levels = [{"level": lv, "ms": round(fw[lv] + bw[lv], 3), "GBps": round(lev_bytes.get(lv, 0) / ((fw[lv] + bw[lv]) * 1e-3) / 1e9, 0) if fw[lv] + bw[lv] > 0 else None}
+                            for lv in range(1, nl + 1)]
+        except Exception as e:  # diagnostics only: never fail the bench line for it
+            solve_levels = "unavailable: %r" % (e,)
 
     # correctness of what was timed: residual of the last solve (never skipped)
     x = b_dev.cpu().numpy()
@@ -548,8 +578,8 @@ def main():
         if world == 1 and t_ldiv > 0 and st["bytes_solve"] > 0:
             # ldiv! is HBM-bound: every stored factor entry is read once per right-hand side
             gbs = st["bytes_solve"] / t_ldiv / 1e9
-            out["solve"] = {"seconds": t_ldiv, "algorithmic_bytes": st["bytes_solve"], "achieved_GBps": gbs,
-                            "frac_of_measured_copy_bw_6290GBps": gbs / 6290.0}
+            out["solve"] = {"seconds": t_ldiv, "algorithmic_bytes": st["bytes_solve"], "achieved_GBps": gbs, "frac_of_spec_8000GBps": gbs / 8000.0,
+                            "frac_of_measured_copy_bw_6290GBps": gbs / 6290.0, "levels": solve_levels}
         if roofline:
             out["roofline"] = roofline
             out["mfma_util_pct"] = 100.0 * roofline["frac"]  # BASELINE.json's metric pairs the time with the MFMA utilisation (FP64-matrix peak 78.6 TF)

@@ -309,14 +309,18 @@ __global__ __launch_bounds__(1024) void wide_first_kernel(const SolveNode<T>* __
 // ------------------------------------------------------------------------------------------------
 // Dataflow sweeps (round 3): ONE launch per tree level and sweep instead of ni/256 dependent launches per front.
 //
-// The launch-per-step sweeps above cost 18-24 us per 256 columns whatever the panel size (307 steps per sweep at Poisson 128^3), and a
-// step is a chain of two dependent 256 x 256 tile products by ONE workgroup (512 KB each: ~6 us) between memory round trips.  Here
-//  * a workgroup of 256 threads OWNS 64 rows of a front for the whole sweep: it accumulates sum_k L[rows, blk k] * y_k in registers as
-//    the y_k arrive, so the tile on the chain is 64 x 256 (128 KB), and four workgroups share what one did per step;
+// The launch-per-step sweeps above cost 18-24 us per 256 columns whatever the panel size (307 steps per sweep at Poisson 128^3): a step is a
+// chain of two dependent 256 x 256 tile products by ONE workgroup between memory round trips.  Here
+//  * a workgroup of 512 threads OWNS 64 rows (ComplexF64: 32) of a front for the whole sweep: it accumulates sum_k L[rows, blk k] * y_k in
+//    registers as the y_k arrive, so a tile is 128 KB, and four (eight) workgroups share what one did per step;
+//  * the tiles do not depend on what is waited for, so the loads of the NEXT tile -- at the end: of the slab of the stored inverse -- are
+//    issued before this round's vector is polled (two register tiles, flow_load / flow_fma): on the chain a round is exchange + FMAs +
+//    one LDS reduction, the memory round trip of its tile is already behind it;
 //  * values are exchanged through two vectors that hold a SENTINEL (all bits set: no arithmetic produces that NaN) until the value is
 //    published with an agent-scope atomic store; a consumer polls the values themselves with agent-scope atomic loads -- no flag, no
-//    fence, one memory round trip per exchange.  E1 carries y (x in the backward sweep), E2 the finished w of a diagonal block: the rows
-//    q*64.. of y_j = inv256_j * w_j need w of the sub-blocks <= q (>= q backward), so a 256-step is tile -> w -> inverse slab -> y;
+//    fence.  Measured (hsk_flow_pingpong_us): 0.5 us per exchange between any two workgroups of the chip, same XCD or not.  E1 carries
+//    y (x in the backward sweep), E2 the finished w of a diagonal block: the rows q*64.. of y_j = inv256_j * w_j need w of the sub-blocks
+//    <= q (>= q backward), so a 256-step is tile -> w -> inverse slab -> y;
 //  * forward progress: a workgroup waits only for sub-blocks of the SAME front that come earlier in the sweep, and workgroup ids are
 //    handed out by an atomic counter in the order the workgroups actually start (block-major, front-minor: all fronts of a level advance
 //    together), so everything a workgroup waits for has started.  Every poll is bounded (HS_FLOW_SPIN rounds of s_sleep, seconds): a
@@ -324,15 +328,18 @@ __global__ __launch_bounds__(1024) void wide_first_kernel(const SolveNode<T>* __
 //    reports it at the next call instead of the GPU hanging.
 // ------------------------------------------------------------------------------------------------
 #define HS_FLOW_SPIN (1 << 22)
-#define HS_FB 64  // rows a workgroup owns
 static constexpr unsigned long long HS_SENT = ~0ull;
-
+// Thread layout of a tile (512 threads = 8 waves): the LANES run along the rows and a WAVE owns 32 consecutive columns, so the column of a
+// load is wave-uniform -- its address is a scalar base plus one per-lane byte offset, and 32 (16) loads in flight cost their data registers
+// only.  Float64: 64 rows, one 8-byte load per lane and column.  ComplexF64: 32 rows, the two half-waves take the two columns of a pair.
 template <class T>
 struct FlowCfg {
-  static constexpr int RP = sizeof(T) == 8 ? 2 : 1;  // rows per thread
-  static constexpr int RT = HS_FB / RP;               // threads along the rows
-  static constexpr int NG = 256 / RT;                 // column groups (8 real, 4 complex)
-  static constexpr int GC = HS_SW / NG;               // columns per group
+  static constexpr int NT = 512;                        // threads per workgroup
+  static constexpr int FB = sizeof(T) == 8 ? 64 : 32;   // rows a workgroup owns: a tile of 256 columns is 128 KB either way
+  static constexpr int SC = 64 / FB;                    // columns a wave covers per load (1 or 2)
+  static constexpr int GC = 32 / SC;                    // loads per thread and tile (32 or 16): 64 data registers
+  static constexpr int NP = (NT / 64) * SC;             // partial sums per row (8 or 16)
+  static constexpr int Q = HS_SW / FB;                  // sub-blocks per 256-block
 };
 __device__ __forceinline__ unsigned long long flow_ldbits(const double* p) {
   return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -344,8 +351,9 @@ __device__ __forceinline__ void flow_publish(cplx* p, cplx v) {
   flow_publish(reinterpret_cast<double*>(p), v.re);
   flow_publish(reinterpret_cast<double*>(p) + 1, v.im);
 }
-// thread t (of 256) fetches element t of a published vector (cnt <= 256 entries) into dst[t], zero beyond cnt; false when the wait ran out
+// thread t < 256 fetches element t of a published vector (cnt <= 256 entries) into dst[t], zero beyond cnt; false when the wait ran out
 __device__ __forceinline__ bool flow_poll(const double* src, int cnt, double* dst, int t) {
+  if (t >= HS_SW) return true;
   if (t >= cnt) {
     dst[t] = 0.0;
     return true;
@@ -361,6 +369,7 @@ __device__ __forceinline__ bool flow_poll(const double* src, int cnt, double* ds
   return false;
 }
 __device__ __forceinline__ bool flow_poll(const cplx* src, int cnt, cplx* dst, int t) {
+  if (t >= HS_SW) return true;
   if (t >= cnt) {
     dst[t] = cplx{0.0, 0.0};
     return true;
@@ -376,69 +385,90 @@ __device__ __forceinline__ bool flow_poll(const cplx* src, int cnt, cplx* dst, i
   }
   return false;
 }
-// s[0..RP) += A[rows of the thread, columns of its group within [c_lo, c_hi)] * sv[...]; `a` points at (first row of the workgroup, column 0 of the block)
+// The thread's share of a tile, in registers: every load issued before anything uses it and none depending on the data the workgroup waits
+// for -- so the tile of the NEXT round is requested before this round's vector is polled (the loop below keeps two of them).  Measured on
+// the way here: with the loads in a loop the compiler issued them in small dependent groups and a 64 x 256 tile cost ~8 us on an idle chip;
+// as one batch ~2.5 us.  Addresses are clamped instead of guarded (rows past rl, columns past `ncol`): what they bring in is multiplied by
+// a zero of the vector or lands in a row nobody stores.  `base` is workgroup-uniform.
+// (buffer loads: the tile base goes into a 128-bit descriptor held in SGPRs, the lane's part of the address is ONE 32-bit byte offset and the
+// column's a scalar offset -- with 64-bit flat addresses the 32 loads in flight of two tiles took 128 address registers and the kernel spilled)
+typedef unsigned int flow_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int flow_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double flow_bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const double*) {
+  const flow_u2 x = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  return __longlong_as_double((long long)(((unsigned long long)x.y << 32) | x.x));
+}
+__device__ __forceinline__ cplx flow_bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const cplx*) {
+  const flow_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return cplx{__longlong_as_double((long long)(((unsigned long long)x.y << 32) | x.x)), __longlong_as_double((long long)(((unsigned long long)x.w << 32) | x.z))};
+}
 template <class T>
-__device__ __forceinline__ void flow_dot(const T* a, size_t ld, int c_lo, int c_hi, const T* sv, int rl, int t, T* s) {
-  constexpr int RP = FlowCfg<T>::RP, RT = FlowCfg<T>::RT, GC = FlowCfg<T>::GC;
-  const int row = (t % RT) * RP, jg = (t / RT) * GC;
-  const int jlo = max(jg, c_lo), jhi = min(jg + GC, c_hi), nrows = min(RP, rl - row);
-  if (jlo == jg && jhi == jg + GC && nrows == RP) {
-    // a full group: every load of the thread issued before the first use -- ONE memory round trip for the tile (the generic loop below goes in
-    // batches of 16 loads: two dependent round trips on a chain where the round trip is what a step costs)
-    const T* p = a + row + (size_t)jg * ld;
-    if constexpr (RP == 2) {
-      hs_d2u v[GC];
+__device__ __forceinline__ void flow_load(T (&v)[FlowCfg<T>::GC], const T* base, unsigned ld, int ncol, int rl, int t) {
+  constexpr int FB = FlowCfg<T>::FB, SC = FlowCfg<T>::SC, GC = FlowCfg<T>::GC;
+  const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const unsigned row = (unsigned)min(lane % FB, rl - 1);
+  // (the descriptor must be PROVABLY uniform or every load becomes a waterfall loop: readfirstlane its inputs)
+  const unsigned long long pb = (unsigned long long)base;
+  const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pb), phi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+  ld = __builtin_amdgcn_readfirstlane(ld);
+  ncol = __builtin_amdgcn_readfirstlane(ncol);
+  const __amdgpu_buffer_rsrc_t r =
+      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(((unsigned long long)phi << 32) | plo), 0, 0x7FFFFFFF, 0x00020000);  // (256 columns of a front: < 2^31 bytes)
+  if constexpr (SC == 1) {
+    const unsigned voff = row * (unsigned)sizeof(T);
 #pragma unroll
-      for (int j = 0; j < GC; ++j) v[j] = gld2(p + (size_t)j * ld);
-#pragma unroll
-      for (int j = 0; j < GC; ++j) {
-        const T y = sv[jg + j];
-        s[0] = Scal<T>::fma(v[j].x, y, s[0]);
-        s[1] = Scal<T>::fma(v[j].y, y, s[1]);
-      }
-    } else {
-      T v[GC];
-#pragma unroll
-      for (int j = 0; j < GC; ++j) v[j] = gld(p + (size_t)j * ld);
-#pragma unroll
-      for (int j = 0; j < GC; ++j) s[0] = Scal<T>::fma(v[j], sv[jg + j], s[0]);
+    for (int j = 0; j < GC; ++j) {
+      const unsigned col = min((unsigned)(wv * 32 + j), (unsigned)(ncol - 1));  // scalar
+      v[j] = flow_bld(r, voff, col * ld * (unsigned)sizeof(T), (const T*)nullptr);
     }
-    return;
-  }
-  wide_dot<T>(a + row, ld, jlo, jhi, sv, nrows, s);
-}
-template <class T>
-__device__ __forceinline__ void flow_put(T* s_red, int t, const T* s) {
-  constexpr int RP = FlowCfg<T>::RP, RT = FlowCfg<T>::RT;
-  const int row = (t % RT) * RP, g = t / RT;
+  } else {
+    const unsigned sc = (unsigned)(lane / FB);
 #pragma unroll
-  for (int q = 0; q < RP; ++q) s_red[g * HS_FB + row + q] = s[q];
+    for (int j = 0; j < GC; ++j) {
+      const unsigned col = min((unsigned)(wv * 32 + j * SC) + sc, (unsigned)(ncol - 1));
+      v[j] = flow_bld(r, (row + col * ld) * (unsigned)sizeof(T), 0u, (const T*)nullptr);
+    }
+  }
 }
 template <class T>
-__device__ __forceinline__ T flow_sum(const T* s_red, int t) {  // t < HS_FB
+__device__ __forceinline__ void flow_fma(const T (&v)[FlowCfg<T>::GC], const T* sv, int t, T& s) {
+  constexpr int FB = FlowCfg<T>::FB, SC = FlowCfg<T>::SC, GC = FlowCfg<T>::GC;
+  const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), sc = lane / FB;
+#pragma unroll
+  for (int j = 0; j < GC; ++j) s = Scal<T>::fma(v[j], sv[wv * 32 + j * SC + sc], s);
+}
+template <class T>
+__device__ __forceinline__ void flow_put(T* s_red, int t, T s) {
+  constexpr int FB = FlowCfg<T>::FB, SC = FlowCfg<T>::SC;
+  const int lane = t & 63, wv = t >> 6;
+  s_red[(wv * SC + lane / FB) * FB + lane % FB] = s;
+}
+template <class T>
+__device__ __forceinline__ T flow_sum(const T* s_red, int t) {  // t < FB
   T v = s_red[t];
 #pragma unroll
-  for (int g = 1; g < FlowCfg<T>::NG; ++g) v = v + s_red[g * HS_FB + t];
+  for (int g = 1; g < FlowCfg<T>::NP; ++g) v = v + s_red[g * FlowCfg<T>::FB + t];
   return v;
 }
 
 // One sweep of one level.  UPPER = false: forward (L below the diagonal, rows down to mrows: the Abi*U^-1 rows update rhs[bnd]);
 // UPPER = true: backward (U above the diagonal).  w: the level's work vector (in: gathered / updated right-hand side), out: y (x).
 template <class T, bool UPPER>
-__global__ __launch_bounds__(256) void flow_sweep_kernel(const SolveNode<T>* __restrict__ nodes, int nbatch, T* __restrict__ w, T* __restrict__ out,
+__global__ __launch_bounds__(512) void flow_sweep_kernel(const SolveNode<T>* __restrict__ nodes, int nbatch, T* __restrict__ w, T* __restrict__ out,
                                                          T* __restrict__ b, T* __restrict__ E1, T* __restrict__ E2, int* __restrict__ counter,
                                                          int* __restrict__ err) {
+  constexpr int FB = FlowCfg<T>::FB, Q = FlowCfg<T>::Q, GC = FlowCfg<T>::GC;
+  using V = T;
   __shared__ int s_id;
   __shared__ T s_v[HS_SW];
-  __shared__ T s_red[HS_FB * FlowCfg<T>::NG];
+  __shared__ T s_red[FB * FlowCfg<T>::NP];
   const int t = threadIdx.x;
   if (t == 0) s_id = atomicAdd(counter, 1);
   __syncthreads();
-  const int id = s_id, f = id % nbatch, sb = id / nbatch;
+  const int id = __builtin_amdgcn_readfirstlane(s_id), f = id % nbatch, sb = id / nbatch;  // (scalar: the front's descriptor and every tile base stay in SGPRs)
   const SolveNode<T> nd = nodes[f];
   if (nd.ni <= 0) return;
   const int ncb = (nd.ni + HS_SW - 1) / HS_SW;
-  constexpr int Q = HS_SW / HS_FB;  // sub-blocks per 256-block
   int jb, q, rs, rl;
   bool interior;
   if (!UPPER) {
@@ -446,21 +476,21 @@ __global__ __launch_bounds__(256) void flow_sweep_kernel(const SolveNode<T>* __r
     if (interior) {
       jb = sb / Q;
       q = sb % Q;
-      rs = jb * HS_SW + q * HS_FB;
-      rl = min(HS_FB, nd.ni - rs);
+      rs = jb * HS_SW + q * FB;
+      rl = min(FB, nd.ni - rs);
     } else {
       jb = ncb;  // all column blocks
       q = 0;
-      rs = nd.ni + (sb - Q * ncb) * HS_FB;
-      rl = min(HS_FB, nd.mrows - rs);
+      rs = nd.ni + (sb - Q * ncb) * FB;
+      rl = min(FB, nd.mrows - rs);
     }
   } else {
     interior = true;
     if (sb >= Q * ncb) return;
     jb = ncb - 1 - sb / Q;
     q = Q - 1 - sb % Q;
-    rs = jb * HS_SW + q * HS_FB;
-    rl = min(HS_FB, nd.ni - rs);
+    rs = jb * HS_SW + q * FB;
+    rl = min(FB, nd.ni - rs);
   }
   if (rl <= 0) return;
   T wold = Scal<T>::zero();
@@ -473,22 +503,55 @@ __global__ __launch_bounds__(256) void flow_sweep_kernel(const SolveNode<T>* __r
       wold = b[gi];
     }
   }
-  constexpr int RP = FlowCfg<T>::RP;
-  T s[RP] = {};
+  T s = Scal<T>::zero();
   const T* arow = nd.LF + (size_t)rs;
   const int kfirst = UPPER ? ncb - 1 : 0, kstep = UPPER ? -1 : 1, kcount = UPPER ? ncb - 1 - jb : jb;
-  for (int c = 0, k = kfirst; c < kcount; ++c, k += kstep) {
+  // what the diagonal block needs: columns [c_lo, c_hi) of the slab of the stored inverse
+  const int wlj = interior ? min(HS_SW, nd.ni - jb * HS_SW) : 1;
+  const int c_lo = UPPER ? q * FB : 0, c_hi = UPPER ? wlj : min(wlj, (q + 1) * FB);
+  const T* inv = interior ? (UPPER ? nd.inv256U : nd.inv256L) + (size_t)jb * HS_SW * HS_SW + (size_t)(q * FB) : nullptr;
+  V va[GC], vb[GC];
+  // requests the tile of round c (c >= kcount: the slab of the inverse; a boundary block has none) into `v`:
+  // one straight run of loads whatever c is -- branches here made the compiler keep four tiles alive and spill
+  const T* tail_base = interior ? inv : arow;
+  const unsigned tail_ld = interior ? (unsigned)HS_SW : (unsigned)nd.ldl;
+  auto request = [&](V(&v)[GC], int c) {
+    const bool last = c >= kcount;
+    if (last && !interior) return;  // (uniform, and no loads at all behind it)
+    const int k = kfirst + (last ? 0 : c) * kstep;
+    const T* base = last ? tail_base : arow + (size_t)k * HS_SW * nd.ldl;
+    const int ncol = (last && interior) ? HS_SW : min(HS_SW, nd.ni - k * HS_SW);
+    flow_load<T>(v, base, last ? tail_ld : (unsigned)nd.ldl, ncol, rl, t);
+  };
+  // round c < kcount: wait for y_k, accumulate; returns false when the wait ran out (uniform)
+  auto round = [&](const V(&v)[GC], int c) -> bool {
+    const int k = kfirst + c * kstep;
     const int wl = min(HS_SW, nd.ni - k * HS_SW);
     const bool ok = flow_poll(E1 + nd.woff + (size_t)k * HS_SW, wl, s_v, t);
-    if (__syncthreads_or(ok ? 0 : 1)) {  // (also publishes s_v to the workgroup)
-      if (t == 0) *(volatile int*)err = 1;  // pinned host memory: a plain store
-      return;
-    }
-#ifdef HS_FLOW_EXPERIMENT_NOBULK  // timing experiment only (wrong results): tiles off the chain are not loaded
-    if (c + 1 >= kcount)
-#endif
-    flow_dot<T>(arow + (size_t)k * HS_SW * nd.ldl, nd.ldl, 0, wl, s_v, rl, t, s);
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(ok ? 0 : 1))) return false;  // (also publishes s_v to the workgroup; readfirstlane: the loop
+                                                                                        // counter must stay provably uniform, or every buffer load turns into a waterfall loop)
+    flow_fma<T>(v, s_v, t, s);
     __syncthreads();  // s_v is refilled by the next round
+    return true;
+  };
+  bool alive = true;
+  int c = 0;
+  if (kcount & 1) {  // an odd count: one round on its own first, so that the pairs below always end with the inverse in `va`
+    request(va, 0);
+    alive = round(va, 0);
+    c = 1;
+  }
+  request(va, c);
+  while (c < kcount && alive) {
+    request(vb, c + 1);
+    alive = round(va, c);
+    request(va, c + 2);  // (c + 2 == kcount: the slab of the inverse, requested before the last y is waited for)
+    if (alive) alive = round(vb, c + 1);
+    c += 2;
+  }
+  if (!alive) {
+    if (t == 0) *(volatile int*)err = 1;  // pinned host memory: a plain store
+    return;
   }
   flow_put<T>(s_red, t, s);
   __syncthreads();
@@ -500,28 +563,25 @@ __global__ __launch_bounds__(256) void flow_sweep_kernel(const SolveNode<T>* __r
   }
   // the diagonal block: publish the finished w of these rows, fetch the sub-blocks the inverse needs, multiply by the slab of the stored inverse
   if (t < rl) flow_publish(E2 + nd.woff + rs + t, wfin);
-  const int wlj = min(HS_SW, nd.ni - jb * HS_SW);
-  const int c_lo = UPPER ? q * HS_FB : 0, c_hi = UPPER ? wlj : min(wlj, (q + 1) * HS_FB);
   bool ok = true;
-  {
-    const int own_lo = q * HS_FB;
-    const bool own = t >= own_lo && t < own_lo + HS_FB;
+  if (t < HS_SW) {
+    const int own_lo = q * FB;
+    const bool own = t >= own_lo && t < own_lo + FB;
     if (!own) {
       if (t >= c_lo && t < c_hi)
         ok = flow_poll(E2 + nd.woff + (size_t)jb * HS_SW, c_hi, s_v, t);  // element t of the block's finished w
       else
         s_v[t] = Scal<T>::zero();
     }
-    if (t < HS_FB) s_v[own_lo + t] = wfin;  // own rows: no round trip (zero beyond rl)
+    if (t < FB) s_v[own_lo + t] = wfin;  // own rows: no round trip (zero beyond rl)
   }
-  if (__syncthreads_or(ok ? 0 : 1)) {
+  if (__builtin_amdgcn_readfirstlane(__syncthreads_or(ok ? 0 : 1))) {
     if (t == 0) *(volatile int*)err = 1;
     return;
   }
   {
-    T s2[RP] = {};
-    const T* inv = (UPPER ? nd.inv256U : nd.inv256L) + (size_t)jb * HS_SW * HS_SW + (size_t)(q * HS_FB);
-    flow_dot<T>(inv, HS_SW, c_lo, c_hi, s_v, rl, t, s2);
+    T s2 = Scal<T>::zero();
+    flow_fma<T>(va, s_v, t, s2);
     flow_put<T>(s_red, t, s2);
   }
   __syncthreads();
@@ -536,14 +596,15 @@ __global__ __launch_bounds__(256) void flow_sweep_kernel(const SolveNode<T>* __r
 template <class T>
 void launch_fwd_flow(const SolveNode<T>* dn, int nbatch, int maxni, int maxnb, T* w, T* y, T* b, T* E1, T* E2, int* counter, int* err, hipStream_t s) {
   if (nbatch <= 0 || maxni <= 0) return;
-  const int nsb = (HS_SW / HS_FB) * ((maxni + HS_SW - 1) / HS_SW) + (std::max(maxnb, 0) + HS_FB - 1) / HS_FB;
-  hipLaunchKernelGGL((flow_sweep_kernel<T, false>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(256), 0, s, dn, nbatch, w, y, b, E1, E2, counter, err);
+  constexpr int FB = FlowCfg<T>::FB;
+  const int nsb = (HS_SW / FB) * ((maxni + HS_SW - 1) / HS_SW) + (std::max(maxnb, 0) + FB - 1) / FB;
+  hipLaunchKernelGGL((flow_sweep_kernel<T, false>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(FlowCfg<T>::NT), 0, s, dn, nbatch, w, y, b, E1, E2, counter, err);
 }
 template <class T>
 void launch_bwd_flow(const SolveNode<T>* dn, int nbatch, int maxni, T* w, T* x, T* E1, T* E2, int* counter, int* err, hipStream_t s) {
   if (nbatch <= 0 || maxni <= 0) return;
-  const int nsb = (HS_SW / HS_FB) * ((maxni + HS_SW - 1) / HS_SW);
-  hipLaunchKernelGGL((flow_sweep_kernel<T, true>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(256), 0, s, dn, nbatch, w, x, (T*)nullptr, E1, E2, counter, err);
+  const int nsb = (HS_SW / FlowCfg<T>::FB) * ((maxni + HS_SW - 1) / HS_SW);
+  hipLaunchKernelGGL((flow_sweep_kernel<T, true>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(FlowCfg<T>::NT), 0, s, dn, nbatch, w, x, (T*)nullptr, E1, E2, counter, err);
 }
 template void launch_fwd_flow<double>(const SolveNode<double>*, int, int, int, double*, double*, double*, double*, double*, int*, int*, hipStream_t);
 template void launch_fwd_flow<cplx>(const SolveNode<cplx>*, int, int, int, cplx*, cplx*, cplx*, cplx*, cplx*, int*, int*, hipStream_t);
