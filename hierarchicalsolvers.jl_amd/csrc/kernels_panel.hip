@@ -454,17 +454,20 @@ __global__ __launch_bounds__(256) void panel_l21_kernel(const NodeDesc<T>* __res
   T a[HS_PB];
 #pragma unroll
   for (int j = 0; j < HS_PB; ++j) a[j] = (j < w) ? base[(size_t)j * nd.ldl] : Scal<T>::zero();
-  T l[HS_PB];
+  // x <- x * inv(U11) IN PLACE, last column first: l[j] needs a[0..j] only, so a[j] can take it.  One register row instead of two: the ComplexF64
+  // instance held 310 registers (256 + 54 AGPRs) -- more than ONE retiring GEMM workgroup frees on a CU (4 waves x 256), so next to a running
+  // trailing update its workgroups waited for BOTH GEMM workgroups of some CU to retire (340 us per launch in the profile of the metric's workload)
+  T(&l)[HS_PB] = a;
   double lmax = 0.0;
 #pragma unroll
-  for (int j = 0; j < HS_PB; ++j) {
+  for (int j = HS_PB - 1; j >= 0; --j) {
     T s = Scal<T>::zero();
 #pragma unroll
     for (int i = 0; i < HS_PB; ++i)
       if (i <= j) s = Scal<T>::fma(a[i], s_iu[i + j * HS_PB], s);
-    l[j] = s;
     if (!(Scal<T>::abs1(s) <= HS_GROWTH_MAX)) lmax = 2.0 * HS_GROWTH_MAX;  // not fmax(): it drops NaN operands, and a NaN multiplier is a violation
     if (j < w) base[(size_t)j * nd.ldl] = s;
+    a[j] = s;
   }
   // fuse & 4: optimistic pivoting -- a row that partial pivoting could have picked (row < pivrows) must not need a
   // multiplier beyond HS_GROWTH_MAX; otherwise the level is redone with tournament pivoting (NaN counts as a violation)

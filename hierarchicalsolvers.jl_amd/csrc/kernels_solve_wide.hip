@@ -55,12 +55,27 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
         const T* Xk = X + k * 1024;
         const T* arow = Aik + (size_t)min(a, wi - 1);  // (clamped: rows past the block's extent multiply by zero below)
         const bool rowok = a < wi;
-#pragma unroll 8
-        for (int q = 0; q < HS_PB; ++q) {
-          T av = gld(arow + (size_t)min(q, wk - 1) * nd.ldl);
-          if (!(rowok && q < wk)) av = Scal<T>::zero();
+        // Float64: all 32 loads of the row before the first use (a register array, fully unrolled) -- in a loop the compiler issued them in
+        // dependent groups, the finding of the dataflow sweeps below (DESIGN.md section 4a'): 284 -> 231 us per call next to the GEMM.
+        // ComplexF64 keeps the loop: batched it measured 2.7 ms instead of 1.1 (its 144 KB of LDS make it wait for both GEMM workgroups of a CU anyway)
+        if constexpr (sizeof(T) == 8) {
+          T av[HS_PB];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) acc[u] = Scal<T>::fma(av, Xk[q + ((t >> 5) + 8 * u) * HS_PB], acc[u]);
+          for (int q = 0; q < HS_PB; ++q) av[q] = gld(arow + (size_t)min(q, wk - 1) * nd.ldl);
+#pragma unroll
+          for (int q = 0; q < HS_PB; ++q) {
+            const T a_ = (rowok && q < wk) ? av[q] : Scal<T>::zero();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = Scal<T>::fma(a_, Xk[q + ((t >> 5) + 8 * u) * HS_PB], acc[u]);
+          }
+        } else {
+#pragma unroll 8
+          for (int q = 0; q < HS_PB; ++q) {
+            T a_ = gld(arow + (size_t)min(q, wk - 1) * nd.ldl);
+            if (!(rowok && q < wk)) a_ = Scal<T>::zero();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = Scal<T>::fma(a_, Xk[q + ((t >> 5) + 8 * u) * HS_PB], acc[u]);
+          }
         }
       }
     }
