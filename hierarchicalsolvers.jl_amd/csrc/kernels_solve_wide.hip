@@ -15,14 +15,27 @@
 // ------------------------------------------------------------------------------------------------
 // inverses of the 256 x 256 diagonal blocks.  grid.x = (256-block, block column j of it), grid.y = front, grid.z = L / U
 // ------------------------------------------------------------------------------------------------
+// A workgroup works on NC of the 32 columns of a block column: 32 for Float64 (72 KB of LDS), 16 for ComplexF64 -- with all 32 a ComplexF64
+// workgroup needed 144 KB, more than ONE retiring GEMM workgroup frees on a CU (54 KB + the 52 KB two of them leave), so next to a running
+// trailing update every workgroup waited for BOTH GEMM workgroups of some CU to retire and then had the CU to itself (1.1 - 5.5 ms per call in
+// the profiles of the complex workloads); with 72 KB it fits beside one.
+template <class T>
+struct Inv256Cfg {
+  static constexpr int NC = sizeof(T) == 8 ? HS_PB : HS_PB / 2;  // columns per workgroup
+  static constexpr int H = HS_PB / NC;                            // workgroups per block column
+  static constexpr int BS = HS_PB * NC;                           // elements of one X block
+  static constexpr int NU = NC / 8;                               // outputs per thread (row t & 31, columns (t >> 5) + 8 u)
+};
 template <class T>
 __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restrict__ nodes, int first_block) {
+  constexpr int NC = Inv256Cfg<T>::NC, H = Inv256Cfg<T>::H, BS = Inv256Cfg<T>::BS, NU = Inv256Cfg<T>::NU;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* X = reinterpret_cast<T*>(smem_raw);   // 8 blocks of 32 x 32 (column-major): X_kj of the current block column
-  T* S = X + 8 * HS_PB * HS_PB;            // 32 x 32 accumulator
+  T* X = reinterpret_cast<T*>(smem_raw);   // 8 blocks of 32 x NC (column-major, ld 32): X_kj of the current block column
+  T* S = X + 8 * BS;                       // 32 x NC accumulator
   const SolveNode<T> nd = nodes[blockIdx.y];
   const int upper = blockIdx.z;
-  const int b256 = first_block + (blockIdx.x >> 3), jc = blockIdx.x & 7;
+  const int sub = blockIdx.x % H, bx = blockIdx.x / H;
+  const int b256 = first_block + (bx >> 3), jc = bx & 7;
   const int c0 = b256 * HS_SW;
   if (c0 >= nd.ni) return;
   const int wl = min(HS_SW, nd.ni - c0);
@@ -33,14 +46,14 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
   T* out = (upper ? nd.inv256U : nd.inv256L) + (size_t)b256 * HS_SW * HS_SW;
   const int sb0 = c0 / HS_PB;  // first 32-block of this wide block
   // X_jj = stored inverse of the diagonal 32-block
-  for (int e = t; e < HS_PB * HS_PB; e += 256) X[jc * 1024 + e] = inv32[(size_t)(sb0 + jc) * 1024 + e];
+  for (int e = t; e < BS; e += 256) X[jc * BS + e] = inv32[(size_t)(sb0 + jc) * 1024 + sub * BS + e];
   __syncthreads();
   const int istep = upper ? -1 : 1;
   for (int i = jc + istep; i >= 0 && i < nsb; i += istep) {
     // S = sum_k A_ik * X_kj over the already known blocks k between j and i
-    T acc[4];
+    T acc[NU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = Scal<T>::zero();
+    for (int u = 0; u < NU; ++u) acc[u] = Scal<T>::zero();
     const int k0 = upper ? i + 1 : jc, k1 = upper ? jc : i - 1;
     // A_ik straight from global memory (round 3): thread t owns ROW a = t & 31 of the block and four of its columns (256 is a multiple of 32), so
     // one load of A_ik[a, q] -- coalesced over the 32 rows -- feeds four outputs, and the loads of all k are independent: no staging through
@@ -52,7 +65,7 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
       for (int k = k0; k <= k1; ++k) {
         const T* Aik = nd.LF + (size_t)(c0 + i * HS_PB) + (size_t)(c0 + k * HS_PB) * nd.ldl;
         const int wk = min(HS_PB, wl - k * HS_PB);
-        const T* Xk = X + k * 1024;
+        const T* Xk = X + k * BS;
         const T* arow = Aik + (size_t)min(a, wi - 1);  // (clamped: rows past the block's extent multiply by zero below)
         const bool rowok = a < wi;
         // Float64: all 32 loads of the row before the first use (a register array, fully unrolled) -- in a loop the compiler issued them in
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
           for (int q = 0; q < HS_PB; ++q) {
             const T a_ = (rowok && q < wk) ? av[q] : Scal<T>::zero();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = Scal<T>::fma(a_, Xk[q + ((t >> 5) + 8 * u) * HS_PB], acc[u]);
+            for (int u = 0; u < NU; ++u) acc[u] = Scal<T>::fma(a_, Xk[q + ((t >> 5) + 8 * u) * HS_PB], acc[u]);
           }
         } else {
 #pragma unroll 8
@@ -74,22 +87,22 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
             T a_ = gld(arow + (size_t)min(q, wk - 1) * nd.ldl);
             if (!(rowok && q < wk)) a_ = Scal<T>::zero();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = Scal<T>::fma(a_, Xk[q + ((t >> 5) + 8 * u) * HS_PB], acc[u]);
+            for (int u = 0; u < NU; ++u) acc[u] = Scal<T>::fma(a_, Xk[q + ((t >> 5) + 8 * u) * HS_PB], acc[u]);
           }
         }
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) S[t + 256 * u] = acc[u];
+    for (int u = 0; u < NU; ++u) S[t + 256 * u] = acc[u];
     __syncthreads();
     // X_ij = -inv32_i * S
     const T* Ii = inv32 + (size_t)(sb0 + i) * 1024;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int e = t + 256 * u, a = e & 31, b = e >> 5;
       T s = Scal<T>::zero();
       for (int q = 0; q < HS_PB; ++q) s = Scal<T>::fma(Ii[a + q * HS_PB], S[q + b * HS_PB], s);
-      X[i * 1024 + e] = Scal<T>::zero() - s;
+      X[i * BS + e] = Scal<T>::zero() - s;
     }
     __syncthreads();
   }
@@ -97,9 +110,9 @@ __global__ __launch_bounds__(256) void inv256_kernel(const SolveNode<T>* __restr
   // case multiplies by the full 256 x 256 block (GemmOp::ainv 3..6)
   const int ilo = upper ? 0 : jc, ihi = upper ? jc : nsb - 1;
   for (int i = 0; i < HS_SW / HS_PB; ++i)
-    for (int e = t; e < HS_PB * HS_PB; e += 256) {
+    for (int e = t; e < BS; e += 256) {
       const int a = e & 31, b = e >> 5;
-      out[(size_t)(i * HS_PB + a) + (size_t)(jc * HS_PB + b) * HS_SW] = (i >= ilo && i <= ihi) ? X[i * 1024 + e] : Scal<T>::zero();
+      out[(size_t)(i * HS_PB + a) + (size_t)(jc * HS_PB + sub * NC + b) * HS_SW] = (i >= ilo && i <= ihi) ? X[i * BS + e] : Scal<T>::zero();
     }
 }
 
@@ -682,13 +695,13 @@ void launch_inv256(const SolveNode<T>* dn, int nbatch, int maxni, hipStream_t s,
   const int first = only_block >= 0 ? only_block : 0;
   const int nb256 = only_block >= 0 ? 1 : (maxni + HS_SW - 1) / HS_SW;
   if (first * HS_SW >= maxni) return;
-  constexpr int lds_bytes = (int)(sizeof(T) * 9 * HS_PB * HS_PB);
+  constexpr int lds_bytes = (int)(sizeof(T) * 9 * Inv256Cfg<T>::BS);
   static bool attr_set = false;
-  if (!attr_set) {  // 72 KiB (double) / 144 KiB (complex) of LDS per workgroup needs the opt-in
+  if (!attr_set) {  // 72 KiB of LDS per workgroup needs the opt-in
     (void)hipFuncSetAttribute((const void*)inv256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL(inv256_kernel<T>, dim3(nb256 * 8, nbatch, 2), dim3(256), lds_bytes, s, dn, first);
+  hipLaunchKernelGGL(inv256_kernel<T>, dim3(nb256 * 8 * Inv256Cfg<T>::H, nbatch, 2), dim3(256), lds_bytes, s, dn, first);
 }
 template <class T>
 void launch_fwd_wide(const SolveNode<T>* dn, int nbatch, int blk, int maxm, T* w, T* y, T* b, hipStream_t s) {
