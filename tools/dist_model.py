@@ -74,6 +74,35 @@ def group_front(ni, nb, g, P):
     return t_end
 
 
+def group_front_analytic(ni, nb, pr, pc, P):
+    """One front on a pr x pc process grid, block-cyclic with blocks of `nb` in both directions (pr = 1: the 1-D column distribution that
+    csrc/hs_dist.h implements), block column by block column with one block column of look-ahead: the step costs the longer of
+      * the trailing update of one rank:  2 (m_rem / pr) (c_rem / pc) w / rate, and
+      * the critical path through the NEXT panel: its own update on its owners, its chain, and the messages that make it usable --
+        the L panel along the process row ((m_rem / pr) w 8 bytes to every peer at once) and, in 2-D, the U panel along the process column.
+    The chain of a 32-column panel costs `chain_us` on one rank (measured next to a running GEMM).  A COLUMN OF RANKS (pr > 1) adds to every
+    32-column panel the pivot reduction over pr ranks (ceil(log2 pr) exchanges of a 32 x 32 candidate block: the tournament of
+    kernels_panel.hip across ranks), one exchange of the pivot rows and the broadcast of the factored diagonal block before the rows below
+    can be divided: (2 + ceil(log2 pr)) latencies of `lat_us` on the chain.  It removes nothing from it: the eliminations of a panel are serial."""
+    import math
+
+    NB = P["nb"]
+    m = ni + nb
+    rate = (P["rate_k256"] if NB <= 256 else P["rate_top"]) * 1e12
+    bw = P["bw"] * 1e9
+    extra = (2 + math.ceil(math.log2(pr))) * P["lat_us"] * 1e-6 if pr > 1 else 0.0
+    t = 0.0
+    for c0 in range(0, ni, NB):
+        w = min(NB, ni - c0)
+        mrem, crem = m - c0 - w, ni + nb - c0 - w
+        chain = (w / 32.0) * (P["chain_us"] * 1e-6 + extra)
+        upd = 2.0 * (mrem / pr) * (crem / pc) * w / rate
+        nxt = 2.0 * (mrem / pr) * w * w / rate
+        msg = (mrem / pr) * w * 8.0 / bw * (1 if pc > 1 else 0) + (w * (crem / pc) * 8.0 / bw if pr > 1 else 0.0)
+        t += max(upd, nxt + chain + msg)
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload", nargs="?", default="poisson3d_128")
@@ -81,6 +110,7 @@ def main():
     ap.add_argument("--nb", type=int, default=1024)
     ap.add_argument("--period", type=int, default=1)
     ap.add_argument("--chain-us", type=float, default=330.0, help="panel chain per 32 columns of a lone front next to a running GEMM (root of 128^3 at the round-2 head)")
+    ap.add_argument("--lat-us", type=float, default=10.0, help="latency of one small inter-GPU exchange on the panel chain of a 2-D layout (pivot reduction, row swap, diagonal block)")
     args = ap.parse_args()
     import hsamd
 
@@ -96,7 +126,7 @@ def main():
             walk(x.right, lv + 1)
 
     walk(nd, 1)
-    P = dict(nb=args.nb, period=args.period, bw=args.bw, chain_us=args.chain_us, nb_la=1024, rate_top=58.0, rate_k256=40.0, rate_schur=64.0, rate_low=48.0)
+    P = dict(nb=args.nb, period=args.period, bw=args.bw, chain_us=args.chain_us, nb_la=1024, rate_top=58.0, rate_k256=40.0, rate_schur=64.0, rate_low=48.0, lat_us=args.lat_us)
     print(f"{args.workload}: {len(levels)} levels; model parameters {P}")
     print(f"{'N':>2} {'subtrees':>9} {'top, first rank (a)':>20} {'top, groups (b)':>16} {'total a':>8} {'total b':>8} {'speed-up a / b':>15}")
     base = None
@@ -120,6 +150,27 @@ def main():
         if base is None:
             base = ta
         print(f"{N:>2} {t_sub:9.3f} {t_a:20.3f} {t_b:16.3f} {ta:8.3f} {tb:8.3f} {base / ta:7.2f} / {base / tb:5.2f}")
+    # 1-D against 2-D for the fronts above the cut ("justify 1-D vs 2-D with the model including a column-of-ranks panel"): the same
+    # analytic step model for both layouts, so that the comparison does not depend on the event simulation above
+    print("\nfronts above the cut, analytic step model, seconds (pr x pc process grid; 1 x g = what hs_dist.h implements):")
+    for lat in sorted({0.0, args.lat_us, 2 * args.lat_us}):
+        P2 = dict(P, lat_us=lat)
+        for N in (2, 4, 8):
+            p = N.bit_length() - 1
+            rows = []
+            grids = [(pr, N // pr) for pr in (1, 2, 4, 8) if pr <= N]
+            for pr, pc in grids:
+                tt = 0.0
+                for lv in range(1, p + 1):
+                    g = N >> (lv - 1)  # ranks of the group that owns a front of this level
+                    gpr = min(pr, g)
+                    tt += group_front_analytic(*levels[lv][0], gpr, max(g // gpr, 1), P2)
+                rows.append(f"{pr}x{pc}: {tt:.3f}")
+            print(f"  lat {lat:4.0f} us, N = {N}:  " + "   ".join(rows))
+    ni1, nb1 = levels[1][0]
+    steps = (ni1 + P['nb'] - 1) // P['nb']
+    print(f"  (the root alone: {steps} block columns x {P['nb'] // 32} panels x {P['chain_us']:.0f} us = {steps * (P['nb'] // 32) * P['chain_us'] * 1e-6:.3f} s of chain on ANY layout; "
+          f"its trailing updates at {P['rate_top']:.0f} TF/s on 8 ranks: {front_flops(ni1, nb1) / (P['rate_top'] * 1e12) / 8:.3f} s)")
 
 
 if __name__ == "__main__":
