@@ -938,6 +938,27 @@ static hs_handle* analyze_impl(int64_t n, const int64_t* colptr, const int64_t* 
       HS_HIP(hipEventCreateWithFlags(&h->ev_cb, hipEventDisableTiming));
     }
     lapa("streams, events");
+    {  // refuse at plan time what cannot fit, and say which flow does: dist_top keeps every group front WHOLE on every rank of its group
+      size_t free_b = 0, total_b = 0;
+      const double need = ((double)fac + (double)inv + (double)sb_total + (double)h->cfs_elems) * sizeof(T);
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0 && need > (double)total_b) {
+        double grp = 0.0;
+        int ngrp = 0;
+        for (const NodeH& x : N)
+          if (x.mine && x.dist) {
+            grp += ((double)x.ldl * x.ni + (double)x.ldu * x.nb + (double)x.nb * x.nb) * sizeof(T);
+            ++ngrp;
+          }
+        if (ngrp > 0)
+          HS_FAIL(HS_ERR_NOMEM, 0,
+                  "OutOfMemoryError: this rank needs %.1f GiB of factors and scratch, the device has %.1f GiB; %.1f GiB of it are %d group fronts that hs_options.dist_top keeps whole on every "
+                  "rank of their group (memory per rank does not shrink with the group).  Use the compressed flow over ranks (hs_options.mf with swlevel != 0: a join ships HSS generators) or "
+                  "dist_top = 0 with more ranks; tools/size_model.py prints the per-rank bytes of every flow",
+                  need / 1073741824.0, (double)total_b / 1073741824.0, grp / 1073741824.0, ngrp);
+        HS_FAIL(HS_ERR_NOMEM, 0, "OutOfMemoryError: this rank needs %.1f GiB of factors and scratch, the device has %.1f GiB (tools/size_model.py prints the per-rank bytes of every flow)",
+                need / 1073741824.0, (double)total_b / 1073741824.0);
+      }
+    }
     dmalloc_arena(&h->d_fac, &h->fac_bytes, fac * sizeof(T), "the factors (LF/UR)");
     lapa("hipMalloc of the factor arena");
     dmalloc_arena(&h->d_inv, &h->inv_bytes, inv * sizeof(T), "the inverse diagonal blocks");

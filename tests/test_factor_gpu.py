@@ -328,3 +328,21 @@ np.save({str(tmp_path / "X0.npy")!r}, hs.ldiv(F, np.load({str(tmp_path / "B.npy"
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
     X0 = np.load(tmp_path / "X0.npy")
     assert relerr(X0, ref) < SOL_TOL and relerr(X, X0) < 1e-11
+
+
+def test_a_plan_that_cannot_fit_is_refused_before_any_allocation(hs):
+    """Poisson 160^3 exact needs ~340 GiB of dense factors: hs_analyze says so (HS_ERR_NOMEM -> MemoryError, with the bytes and where the
+    per-rank sizes of every flow can be looked up) instead of failing somewhere inside hipMalloc."""
+    import time
+
+    P = prepare(hs, (160, 160, 160), kind="poisson", nmax=4096)
+    t0 = time.perf_counter()
+    with pytest.raises(MemoryError) as e:
+        hs.factor(P["A"], P["nd"], P["nd_loc"], swlevel=0)
+    msg = str(e.value)
+    assert "GiB" in msg and "size_model" in msg, msg
+    assert time.perf_counter() - t0 < 60.0
+    # the library is still usable afterwards
+    P2 = prepare(hs, (12, 11, 10), kind="poisson", nmax=60)
+    F = hs.factor(P2["A"], P2["nd"], P2["nd_loc"], swlevel=0)
+    assert relerr(hs.ldiv(F, P2["b"]), spla.splu(P2["A"]).solve(P2["b"])) < SOL_TOL
