@@ -479,6 +479,13 @@ __device__ __forceinline__ T flow_sum(const T* s_red, int t) {  // t < FB
   return v;
 }
 
+#ifdef HS_FLOW_TRACE  // timing experiment: device timestamps (100 MHz) of the chain phases of front 0, forward sweep: 8 slots per interior sub-block
+__device__ unsigned long long g_flow_trace[8 * 4096];
+extern "C" int hsk_flow_trace(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1; }
+#define FLOW_T(slot) do { if (!UPPER && f == 0 && nbatch == 1 && interior && t == 0 && sb < 4096) g_flow_trace[8 * sb + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FLOW_T(slot) do { } while (0)
+#endif
 // One sweep of one level.  UPPER = false: forward (L below the diagonal, rows down to mrows: the Abi*U^-1 rows update rhs[bnd]);
 // UPPER = true: backward (U above the diagonal).  w: the level's work vector (in: gathered / updated right-hand side), out: y (x).
 template <class T, bool UPPER>
@@ -577,6 +584,7 @@ __global__ __launch_bounds__(512) void flow_sweep_kernel(const SolveNode<T>* __r
     if (alive) alive = round(vb, c + 1);
     c += 2;
   }
+  FLOW_T(0);  // last round done (y of the block before arrived, FMAs done)
   if (!alive) {
     if (t == 0) *(volatile int*)err = 1;  // pinned host memory: a plain store
     return;
@@ -591,6 +599,7 @@ __global__ __launch_bounds__(512) void flow_sweep_kernel(const SolveNode<T>* __r
   }
   // the diagonal block: publish the finished w of these rows, fetch the sub-blocks the inverse needs, multiply by the slab of the stored inverse
   if (t < rl) flow_publish(E2 + nd.woff + rs + t, wfin);
+  FLOW_T(1);  // w published
   bool ok = true;
   if (t < HS_SW) {
     const int own_lo = q * FB;
@@ -607,6 +616,7 @@ __global__ __launch_bounds__(512) void flow_sweep_kernel(const SolveNode<T>* __r
     if (t == 0) *(volatile int*)err = 1;
     return;
   }
+  FLOW_T(2);  // w of the block arrived
   {
     T s2 = Scal<T>::zero();
     flow_fma<T>(va, s_v, t, s2);
@@ -617,6 +627,7 @@ __global__ __launch_bounds__(512) void flow_sweep_kernel(const SolveNode<T>* __r
     const T v = flow_sum<T>(s_red, t);
     flow_publish(E1 + nd.woff + rs + t, v);
     out[nd.woff + rs + t] = v;
+    FLOW_T(3);  // y published
     if (!UPPER) w[nd.woff + rs + t] = wfin;  // (what the launch-per-step sweep leaves behind: nothing reads it, kept for identical buffers)
   }
 }
