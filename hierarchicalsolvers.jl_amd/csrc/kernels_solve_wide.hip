@@ -362,11 +362,15 @@ static constexpr unsigned long long HS_SENT = ~0ull;
 // only.  Float64: 64 rows, one 8-byte load per lane and column.  ComplexF64: 32 rows, the two half-waves take the two columns of a pair.
 template <class T>
 struct FlowCfg {
-  static constexpr int NT = 512;                        // threads per workgroup
-  static constexpr int FB = sizeof(T) == 8 ? 64 : 32;   // rows a workgroup owns: a tile of 256 columns is 128 KB either way
-  static constexpr int SC = 64 / FB;                    // columns a wave covers per load (1 or 2)
-  static constexpr int GC = 32 / SC;                    // loads per thread and tile (32 or 16): 64 data registers
-  static constexpr int NP = (NT / 64) * SC;             // partial sums per row (8 or 16)
+#ifndef HS_FLOW_NT
+#define HS_FLOW_NT 512
+#endif
+  static constexpr int NT = HS_FLOW_NT;                 // threads per workgroup
+  static constexpr int FB = (sizeof(T) == 8 ? 64 : 32) * NT / 512;  // rows a workgroup owns: 64 data registers per thread and tile either way
+  static constexpr int SC = 64 / FB;                    // columns a wave covers per load
+  static constexpr int CW = HS_SW / (NT / 64);          // columns a wave owns
+  static constexpr int GC = CW / SC;                    // loads per thread and tile: 64 data registers
+  static constexpr int NP = (NT / 64) * SC;             // partial sums per row
   static constexpr int Q = HS_SW / FB;                  // sub-blocks per 256-block
 };
 __device__ __forceinline__ unsigned long long flow_ldbits(const double* p) {
@@ -446,14 +450,14 @@ __device__ __forceinline__ void flow_load(T (&v)[FlowCfg<T>::GC], const T* base,
     const unsigned voff = row * (unsigned)sizeof(T);
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
-      const unsigned col = min((unsigned)(wv * 32 + j), (unsigned)(ncol - 1));  // scalar
+      const unsigned col = min((unsigned)(wv * FlowCfg<T>::CW + j), (unsigned)(ncol - 1));  // scalar
       v[j] = flow_bld(r, voff, col * ld * (unsigned)sizeof(T), (const T*)nullptr);
     }
   } else {
     const unsigned sc = (unsigned)(lane / FB);
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
-      const unsigned col = min((unsigned)(wv * 32 + j * SC) + sc, (unsigned)(ncol - 1));
+      const unsigned col = min((unsigned)(wv * FlowCfg<T>::CW + j * SC) + sc, (unsigned)(ncol - 1));
       v[j] = flow_bld(r, (row + col * ld) * (unsigned)sizeof(T), 0u, (const T*)nullptr);
     }
   }
@@ -463,7 +467,7 @@ __device__ __forceinline__ void flow_fma(const T (&v)[FlowCfg<T>::GC], const T* 
   constexpr int FB = FlowCfg<T>::FB, SC = FlowCfg<T>::SC, GC = FlowCfg<T>::GC;
   const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), sc = lane / FB;
 #pragma unroll
-  for (int j = 0; j < GC; ++j) s = Scal<T>::fma(v[j], sv[wv * 32 + j * SC + sc], s);
+  for (int j = 0; j < GC; ++j) s = Scal<T>::fma(v[j], sv[wv * FlowCfg<T>::CW + j * SC + sc], s);
 }
 template <class T>
 __device__ __forceinline__ void flow_put(T* s_red, int t, T s) {
@@ -489,7 +493,7 @@ extern "C" int hsk_flow_trace(unsigned long long* out, int n) { return hipMemcpy
 // One sweep of one level.  UPPER = false: forward (L below the diagonal, rows down to mrows: the Abi*U^-1 rows update rhs[bnd]);
 // UPPER = true: backward (U above the diagonal).  w: the level's work vector (in: gathered / updated right-hand side), out: y (x).
 template <class T, bool UPPER>
-__global__ __launch_bounds__(512) void flow_sweep_kernel(const SolveNode<T>* __restrict__ nodes, int nbatch, T* __restrict__ w, T* __restrict__ out,
+__global__ __launch_bounds__(HS_FLOW_NT) void flow_sweep_kernel(const SolveNode<T>* __restrict__ nodes, int nbatch, T* __restrict__ w, T* __restrict__ out,
                                                          T* __restrict__ b, T* __restrict__ E1, T* __restrict__ E2, int* __restrict__ counter,
                                                          int* __restrict__ err) {
   constexpr int FB = FlowCfg<T>::FB, Q = FlowCfg<T>::Q, GC = FlowCfg<T>::GC;
