@@ -483,6 +483,43 @@ __device__ __forceinline__ T flow_sum(const T* s_red, int t) {  // t < FB
   return v;
 }
 
+// The rows of the Gauss transform (rows >= ni of the forward sweep: rhs[bnd] -= (Abi*U^-1) * y) depend on nothing but the y they multiply, and they
+// are most of what the forward sweep reads.  They are walked in TALL tiles -- FBB = 256 (ComplexF64: 128) rows x 64 columns, 128 KB like the tiles of
+// the chain -- because what limits these rounds is DRAM efficiency, and a column of a tall tile is 2 KB of consecutive addresses instead of 512 bytes
+// (measured with 32-row blocks, i.e. 256-byte segments: 29.6 ms instead of 27.6).  Lanes along 64 rows, RG row groups, CG column groups per workgroup.
+template <class T>
+struct FlowBCfg {
+  static constexpr int FBB = sizeof(T) == 8 ? 256 : 128;  // rows of a boundary block
+  static constexpr int RG = FBB / 64;                      // row groups (waves along the rows)
+  static constexpr int CG = (FlowCfg<T>::NT / 64) / RG;    // column groups
+  static constexpr int CT = 64;                            // columns of a tile
+  static constexpr int GC = CT / CG;                       // loads per thread and tile (32 / 16): 64 data registers
+};
+template <class T>
+__device__ __forceinline__ void flow_load_b(T (&v)[FlowBCfg<T>::GC], const T* base, unsigned ld, int ncol, int rl, int t) {
+  constexpr int RG = FlowBCfg<T>::RG, GC = FlowBCfg<T>::GC;
+  const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), rg = wv % RG, cg = wv / RG;
+  const unsigned row = (unsigned)min(rg * 64 + lane, rl - 1);
+  const unsigned long long pb = (unsigned long long)base;
+  const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pb), phi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+  ld = __builtin_amdgcn_readfirstlane(ld);
+  ncol = __builtin_amdgcn_readfirstlane(ncol);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(((unsigned long long)phi << 32) | plo), 0, 0x7FFFFFFF, 0x00020000);
+  const unsigned voff = row * (unsigned)sizeof(T);
+#pragma unroll
+  for (int j = 0; j < GC; ++j) {
+    const unsigned col = min((unsigned)(cg * GC + j), (unsigned)(ncol - 1));  // scalar
+    v[j] = flow_bld(r, voff, col * ld * (unsigned)sizeof(T), (const T*)nullptr);
+  }
+}
+template <class T>
+__device__ __forceinline__ void flow_fma_b(const T (&v)[FlowBCfg<T>::GC], const T* sv, int t, T& s) {
+  constexpr int RG = FlowBCfg<T>::RG, GC = FlowBCfg<T>::GC;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6), cg = wv / RG;
+#pragma unroll
+  for (int j = 0; j < GC; ++j) s = Scal<T>::fma(v[j], sv[cg * GC + j], s);
+}
+
 #ifdef HS_FLOW_TRACE  // timing experiment: device timestamps (100 MHz) of the chain phases of front 0, forward sweep: 8 slots per interior sub-block
 __device__ unsigned long long g_flow_trace[8 * 4096];
 extern "C" int hsk_flow_trace(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1; }
@@ -495,7 +532,7 @@ extern "C" int hsk_flow_trace(unsigned long long* out, int n) { return hipMemcpy
 template <class T, bool UPPER>
 __global__ __launch_bounds__(HS_FLOW_NT) void flow_sweep_kernel(const SolveNode<T>* __restrict__ nodes, int nbatch, T* __restrict__ w, T* __restrict__ out,
                                                          T* __restrict__ b, T* __restrict__ E1, T* __restrict__ E2, int* __restrict__ counter,
-                                                         int* __restrict__ err) {
+                                                         int* __restrict__ err, int tall) {
   constexpr int FB = FlowCfg<T>::FB, Q = FlowCfg<T>::Q, GC = FlowCfg<T>::GC;
   using V = T;
   __shared__ int s_id;
@@ -520,8 +557,9 @@ __global__ __launch_bounds__(HS_FLOW_NT) void flow_sweep_kernel(const SolveNode<
     } else {
       jb = ncb;  // all column blocks
       q = 0;
-      rs = nd.ni + (sb - Q * ncb) * FB;
-      rl = min(FB, nd.mrows - rs);
+      const int fbb = tall ? FlowBCfg<T>::FBB : FB;  // tall boundary tiles only where the level has enough of them to fill the chip (launch_fwd_flow)
+      rs = nd.ni + (sb - Q * ncb) * fbb;
+      rl = min(fbb, nd.mrows - rs);
     }
   } else {
     interior = true;
@@ -532,6 +570,63 @@ __global__ __launch_bounds__(HS_FLOW_NT) void flow_sweep_kernel(const SolveNode<
     rl = min(FB, nd.ni - rs);
   }
   if (rl <= 0) return;
+  if (!UPPER && !interior && tall) {  // tall tiles: FBB rows x 64 columns (FlowBCfg)
+    constexpr int FBB = FlowBCfg<T>::FBB, RG = FlowBCfg<T>::RG, CG = FlowBCfg<T>::CG, CT = FlowBCfg<T>::CT, GB = FlowBCfg<T>::GC;
+    static_assert(FBB * CG <= FlowCfg<T>::FB * FlowCfg<T>::NP, "the partial sums of a boundary block must fit s_red");
+    T wold_b = Scal<T>::zero();
+    int gi_b = 0;
+    if (t < rl) {
+      gi_b = gld(nd.fidx + rs + t);
+      wold_b = b[gi_b];
+    }
+    const T* brow = nd.LF + (size_t)rs;
+    const int nr = (nd.ni + CT - 1) / CT;  // rounds: 64 columns each
+    T sb_ = Scal<T>::zero();
+    T ua[GB], ub[GB];
+    auto request_b = [&](T(&v)[GB], int c) {
+      if (c >= nr) return;
+      flow_load_b<T>(v, brow + (size_t)c * CT * nd.ldl, (unsigned)nd.ldl, min(CT, nd.ni - c * CT), rl, t);
+    };
+    auto round_b = [&](const T(&v)[GB], int c) -> bool {
+      const int wl = min(CT, nd.ni - c * CT);
+      const bool ok = t < CT ? flow_poll(E1 + nd.woff + (size_t)c * CT, wl, s_v, t) : true;
+      if (__builtin_amdgcn_readfirstlane(__syncthreads_or(ok ? 0 : 1))) return false;
+      flow_fma_b<T>(v, s_v, t, sb_);
+      __syncthreads();
+      return true;
+    };
+    bool alive_b = true;
+    int c = 0;
+    if (nr & 1) {
+      request_b(ua, 0);
+      alive_b = round_b(ua, 0);
+      c = 1;
+    }
+    request_b(ua, c);
+    while (c < nr && alive_b) {
+      request_b(ub, c + 1);
+      alive_b = round_b(ua, c);
+      request_b(ua, c + 2);
+      if (alive_b) alive_b = round_b(ub, c + 1);
+      c += 2;
+    }
+    if (!alive_b) {
+      if (t == 0) *(volatile int*)err = 1;
+      return;
+    }
+    {  // partial sums of the CG column groups meet in LDS
+      const int lane = t & 63, wv = t >> 6, rg = wv % RG, cg = wv / RG;
+      s_red[cg * FBB + rg * 64 + lane] = sb_;
+    }
+    __syncthreads();
+    if (t < rl) {
+      T v = s_red[t];
+#pragma unroll
+      for (int g = 1; g < CG; ++g) v = v + s_red[g * FBB + t];
+      b[gi_b] = wold_b - v;
+    }
+    return;
+  }
   T wold = Scal<T>::zero();
   int gi = 0;
   if (t < rl) {  // ahead of the tiles
@@ -639,15 +734,19 @@ __global__ __launch_bounds__(HS_FLOW_NT) void flow_sweep_kernel(const SolveNode<
 template <class T>
 void launch_fwd_flow(const SolveNode<T>* dn, int nbatch, int maxni, int maxnb, T* w, T* y, T* b, T* E1, T* E2, int* counter, int* err, hipStream_t s) {
   if (nbatch <= 0 || maxni <= 0) return;
-  constexpr int FB = FlowCfg<T>::FB;
-  const int nsb = (HS_SW / FB) * ((maxni + HS_SW - 1) / HS_SW) + (std::max(maxnb, 0) + FB - 1) / FB;
-  hipLaunchKernelGGL((flow_sweep_kernel<T, false>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(FlowCfg<T>::NT), 0, s, dn, nbatch, w, y, b, E1, E2, counter, err);
+  constexpr int FB = FlowCfg<T>::FB, FBB = FlowBCfg<T>::FBB;
+  // tall boundary tiles (2 KB column segments) where the level has enough boundary blocks to fill the chip several times; at the top of the tree a
+  // tall block is a serial walk over ni/64 rounds with too few workgroups beside it (measured: levels 2-4 of Poisson 128^3 20 % slower, the leaf level 4 % faster)
+  const int tall = (long long)nbatch * ((std::max(maxnb, 0) + FBB - 1) / FBB) >= 1536 ? 1 : 0;
+  const int fbb = tall ? FBB : FB;
+  const int nsb = (HS_SW / FB) * ((maxni + HS_SW - 1) / HS_SW) + (std::max(maxnb, 0) + fbb - 1) / fbb;
+  hipLaunchKernelGGL((flow_sweep_kernel<T, false>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(FlowCfg<T>::NT), 0, s, dn, nbatch, w, y, b, E1, E2, counter, err, tall);
 }
 template <class T>
 void launch_bwd_flow(const SolveNode<T>* dn, int nbatch, int maxni, T* w, T* x, T* E1, T* E2, int* counter, int* err, hipStream_t s) {
   if (nbatch <= 0 || maxni <= 0) return;
   const int nsb = (HS_SW / FlowCfg<T>::FB) * ((maxni + HS_SW - 1) / HS_SW);
-  hipLaunchKernelGGL((flow_sweep_kernel<T, true>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(FlowCfg<T>::NT), 0, s, dn, nbatch, w, x, (T*)nullptr, E1, E2, counter, err);
+  hipLaunchKernelGGL((flow_sweep_kernel<T, true>), dim3((unsigned)nsb * (unsigned)nbatch), dim3(FlowCfg<T>::NT), 0, s, dn, nbatch, w, x, (T*)nullptr, E1, E2, counter, err, 0);
 }
 template void launch_fwd_flow<double>(const SolveNode<double>*, int, int, int, double*, double*, double*, double*, double*, int*, int*, hipStream_t);
 template void launch_fwd_flow<cplx>(const SolveNode<cplx>*, int, int, int, cplx*, cplx*, cplx*, cplx*, cplx*, int*, int*, hipStream_t);
