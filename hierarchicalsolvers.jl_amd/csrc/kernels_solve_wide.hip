@@ -1,4 +1,6 @@
-// kernels_solve_wide.hip -- the triangular sweeps of ldiv! advancing 256 columns per launch.
+// kernels_solve_wide.hip -- the triangular sweeps of ldiv!: inverses of the 256 x 256 diagonal blocks (inv256_kernel), the sweeps advancing 256
+// columns per launch (fwd_wide / bwd_wide: HS_SOLVE_FLOW=0), and -- the default since round 3 -- the sweeps of a whole tree level as ONE
+// dataflow launch (flow_sweep_kernel, second half of the file; DESIGN.md section 4a').
 //
 // Reference: `_lsolve!` / `_dsolve!` / `_rsolve!` (src/factornode.jl:77-99); kernels_solve.hip has the 32-column
 // version of the same right-looking sweeps.  A 32-column step moves at most 8 MB (a 32,768-row panel), far too little to
