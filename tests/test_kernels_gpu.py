@@ -151,3 +151,15 @@ def test_front_singular_flag(hs):
 def test_mfma_peak_probe(hs):
     tf = hs._lib.lib().hsk_mfma_f64_peak(2, 20000)
     assert tf > 10.0, tf
+
+
+def test_flow_exchange_primitive_round_trip(hs):
+    """hsk_flow_pingpong_us: two workgroups of one launch answer each other through agent-scope atomic stores and polled loads -- the exchange
+    primitive of the dataflow sweeps of ldiv! (kernels_solve_wide.hip).  Every poll is bounded, so the call returns whatever happens; a round trip
+    is ~1 us on MI355X (DESIGN.md section 4a'), same XCD (peer 8) or not (peer 1)."""
+    L = hs._lib.lib()
+    for peer in (1, 8, 255):
+        us = L.hsk_flow_pingpong_us(peer, 2000)
+        print(f"peer {peer}: {us:.3f} us per round trip")
+        assert 0.05 < us < 50.0, (peer, us)
+    assert L.hsk_flow_pingpong_us(0, 10) < 0  # argument check
